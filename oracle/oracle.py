@@ -1,0 +1,196 @@
+"""numpy front-end of the CPU oracle (oracle/libmot_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` -- never by the product package.  Each function
+is a thin ctypes call into ``mot_oracle.c``, whose comments cite the reference lines
+it restates (all under /root/reference, which is not needed at run time).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "libmot_oracle.so"
+
+MODE_NOOP, MODE_SUM, MODE_MEAN, MODE_CONCAT_LINEAR = 0, 1, 2, 3
+_MODES = {"noop": MODE_NOOP, "sum": MODE_SUM, "mean": MODE_MEAN, "concat_linear": MODE_CONCAT_LINEAR}
+
+
+def build(force: bool = False) -> Path:
+    """Compile the oracle with gcc (a few seconds); no-op when up to date."""
+    srcs = [_HERE / "mot_oracle.c", _HERE / "mot_oracle_float.inc"]
+    if force or not _LIB_PATH.exists() or any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists():
+            build()
+        _lib = C.CDLL(str(_LIB_PATH))
+    return _lib
+
+
+def set_threads(n: int) -> None:
+    """OpenMP thread count for the timed cpu_baseline (libgomp reads the env lazily)."""
+    os.environ["OMP_NUM_THREADS"] = str(n)
+    try:
+        C.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+def _check(rc: int, what: str):
+    if rc == -1:
+        raise AssertionError(f"{what}: bad shape (reference asserts here)")
+    if rc == -3:
+        raise IndexError(f"{what}: index out of range")
+    if rc != 0:
+        raise RuntimeError(f"{what}: oracle error {rc}")
+
+
+def tokens_to_bytes(tokens: np.ndarray, table_f32: np.ndarray) -> np.ndarray:
+    """data_creation.py:61-67.  2-D tokens -> (B, T*bpt); 1-D -> (1, T*bpt)."""
+    tok = _c(tokens, np.int32)
+    tab = _c(table_f32, np.float32)
+    vocab, bpt = tab.shape
+    out = np.empty(tok.size * bpt, dtype=np.int64)
+    _check(lib().oracle_tokens_to_bytes(_p(tok, C.c_int32), _p(tab, C.c_float), C.c_int64(vocab),
+                                        C.c_int64(tok.size), C.c_int(bpt), _p(out, C.c_int64)),
+           "tokens_to_bytes")
+    return out.reshape(tok.shape[0], -1) if tok.ndim == 2 else out.reshape(1, -1)
+
+
+def _pull(fn, byte_tensor, bpt, pad, eot):
+    x = _c(byte_tensor, np.int64)
+    assert x.ndim == 2
+    B, T = x.shape
+    if T == 0:
+        return x
+    out = np.empty_like(x)
+    _check(fn(_p(x, C.c_int64), C.c_int64(B), C.c_int64(T), C.c_int(bpt), C.c_int64(pad), C.c_int64(eot),
+              _p(out, C.c_int64)), "pull")
+    return out
+
+
+def pull_from_left(byte_tensor, bytes_per_token, pad_byte, eot_byte):
+    """data_creation.py:179-305."""
+    return _pull(lib().oracle_pull_from_left, byte_tensor, bytes_per_token, pad_byte, eot_byte)
+
+
+def pull_from_right(byte_tensor, bytes_per_token, pad_byte, eot_byte):
+    """data_creation.py:71-176."""
+    return _pull(lib().oracle_pull_from_right, byte_tensor, bytes_per_token, pad_byte, eot_byte)
+
+
+def create_batch(tokens, bytes_per_token, pad_byte, eot_byte, table_right_f32, table_left_f32):
+    """data_creation.py:308-330 (argument order as the reference: right table, then left)."""
+    tok = _c(tokens, np.int32)
+    B, T = tok.shape
+    tl, tr = _c(table_left_f32, np.float32), _c(table_right_f32, np.float32)
+    out = np.empty((B, T, 1 + 4 * bytes_per_token), dtype=np.int64)
+    _check(lib().oracle_create_batch(_p(tok, C.c_int32), _p(tl, C.c_float), _p(tr, C.c_float),
+                                     C.c_int64(tl.shape[0]), C.c_int64(B), C.c_int64(T), C.c_int(bytes_per_token),
+                                     C.c_int64(pad_byte), C.c_int64(eot_byte), _p(out, C.c_int64)), "create_batch")
+    return out
+
+
+def byte_stats(padded, pulled, pad_byte):
+    """runs/79_mot-in_toks-valemb.py:484-488 -> (total, pads_before, pads_after)."""
+    a, b = _c(padded, np.int64).ravel(), _c(pulled, np.int64).ravel()
+    st = np.zeros(3, dtype=np.int64)
+    lib().oracle_byte_stats(_p(a, C.c_int64), _p(b, C.c_int64), C.c_int64(a.size), C.c_int64(pad_byte),
+                            _p(st, C.c_int64))
+    return st
+
+
+def tokens_to_digits(tokens, length_factor):
+    """mathblations/data.py:92-109."""
+    tok = _c(tokens, np.int64)
+    out = np.empty(tok.size * length_factor, dtype=np.int64)
+    _check(lib().oracle_tokens_to_digits(_p(tok, C.c_int64), C.c_int64(tok.size), C.c_int(length_factor),
+                                         _p(out, C.c_int64)), "tokens_to_digits")
+    return out.reshape(*tok.shape[:-1], -1) if tok.ndim > 1 else out
+
+
+def rank_slice_shift(data, pos, batch, seq, rank, world):
+    """train_gpt.py:795-805 + the [:, :-1] / [:, 1:] shift of 692-764."""
+    d = _c(data, np.int32)
+    assert batch % world == 0
+    rows = batch // world
+    assert pos + (rank + 1) * rows * (seq + 1) <= d.size
+    ti = np.empty((rows, seq), dtype=np.int32)
+    tg = np.empty((rows, seq), dtype=np.int32)
+    _check(lib().oracle_rank_slice_shift(_p(d, C.c_int32), C.c_int64(pos), C.c_int64(batch), C.c_int64(seq),
+                                         C.c_int(rank), C.c_int(world), _p(ti, C.c_int32), _p(tg, C.c_int32)),
+           "rank_slice_shift")
+    return ti, tg
+
+
+def embed_mix(tokens, ids_a, ids_b, tok_table, byte_table, *, mode, bpt, weight=None, bias=None,
+              bytes_first=False, norm_tok=False, norm_byte=False, norm_out=False,
+              scale_tok=1.0, scale_byte=1.0, dtype=np.float32, return_seam=False):
+    """Float path; see mot_oracle_float.inc for the formula and reference lines.
+
+    tokens (...,) int; ids_a/ids_b (..., bpt) or (B, T*bpt) int (ids_b optional);
+    tables in ``dtype`` (float32 -> the fp32 oracle, float64 -> the exact one).
+    """
+    real = C.c_float if dtype == np.float32 else C.c_double
+    fn = lib().oracle_embed_mix_f32 if dtype == np.float32 else lib().oracle_embed_mix_f64
+    tok = _c(tokens, np.int32)
+    n = tok.size
+    tt = _c(tok_table, dtype)
+    Dt = tt.shape[1]
+    m = _MODES[mode]
+    if m == MODE_NOOP:
+        bt = np.zeros((1, 1), dtype=dtype)
+        ia = None
+        ib = None
+        bpt_ = 0
+    else:
+        bt = _c(byte_table, dtype)
+        ia = _c(ids_a, np.int64).reshape(-1)
+        ib = None if ids_b is None else _c(ids_b, np.int64).reshape(-1)
+        bpt_ = bpt
+        assert ia.size == n * bpt
+    Db = bt.shape[1]
+    if m == MODE_CONCAT_LINEAR:
+        w = _c(weight, dtype)
+        Dm = w.shape[0]
+        assert w.shape[1] == Dt + bpt_ * Db, (w.shape, Dt, bpt_, Db)
+    else:
+        w = None
+        Dm = Dt
+    bs = None if bias is None else _c(bias, dtype)
+    out = np.empty((n, Dm), dtype=dtype)
+    te = np.empty((n, Dt), dtype=dtype) if return_seam else None
+    be = np.empty((n * bpt_, Db), dtype=dtype) if (return_seam and m != MODE_NOOP) else None
+    _check(fn(_p(tok, C.c_int32), C.c_int64(n), _p(ia, C.c_int64), _p(ib, C.c_int64), C.c_int(bpt_),
+              _p(tt, real), C.c_int64(tt.shape[0]), C.c_int(Dt),
+              _p(bt, real), C.c_int64(bt.shape[0]), C.c_int(Db),
+              C.c_int(m), C.c_int(int(bytes_first)), _p(w, real), _p(bs, real), C.c_int(Dm),
+              C.c_int(int(norm_tok)), C.c_int(int(norm_byte)), C.c_int(int(norm_out)),
+              C.c_double(scale_tok), C.c_double(scale_byte),
+              _p(out, real), _p(te, real), _p(be, real)), "embed_mix")
+    out = out.reshape(*tok.shape, Dm)
+    if return_seam:
+        return out, te.reshape(*tok.shape, Dt), (None if be is None else be.reshape(*tok.shape[:-1], -1, Db))
+    return out

@@ -1,0 +1,191 @@
+"""Pins the CPU oracle (oracle/mot_oracle.c) against fixtures the reference itself produced
+(oracle/gen_golden.py ran /root/reference on these inputs; see tests/golden/META.json).
+
+Bars: integer/index tensors bit-exact; fp32 float path within rtol=1e-6, atol=1e-6 of the
+reference's fp32 output for the gather+sum+norm family, and the float64 oracle within 1e-12
+of the reference's float64 output for everything.  The fp32 concat+linear outputs are
+compared with the reference's fp32 at 2e-5 (the reference's own fp32 GEMM sits up to ~4e-6
+from its float64 evaluation) and with its float64 output at 2e-6.
+"""
+import numpy as np
+import pytest
+
+import golden_inputs as gi
+from oracle import oracle as orc
+
+G = gi.GOLDEN_DIR
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float64).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def index():
+    return np.load(G / "index.npz")
+
+
+def ttb_f32(tab):
+    return tab.astype(np.float32)
+
+
+def test_real_vocab_index(index):
+    tl = gi.load_real_ttb8()
+    tr = gi.to_right_pad(tl)
+    toks = index["real/tokens"]
+    for side, tab, pull in (("left", tl, orc.pull_from_left), ("right", tr, orc.pull_from_right)):
+        padded = orc.tokens_to_bytes(toks, ttb_f32(tab))
+        assert padded.dtype == np.int64
+        np.testing.assert_array_equal(padded, index[f"real/{side}/padded"])
+        np.testing.assert_array_equal(pull(padded, 8, gi.PAD, gi.EOT), index[f"real/{side}/pulled"])
+    np.testing.assert_array_equal(orc.tokens_to_bytes(toks[0], ttb_f32(tl)), index["real/left/padded_1d"])
+    t16 = gi.widen_left_pad(tl, 16)
+    padded = orc.tokens_to_bytes(toks, ttb_f32(t16))
+    np.testing.assert_array_equal(padded, index["real16/left/padded"])
+    np.testing.assert_array_equal(orc.pull_from_left(padded, 16, gi.PAD, gi.EOT), index["real16/left/pulled"])
+
+
+@pytest.mark.parametrize("case", gi.SYNTH_INDEX_CASES, ids=lambda c: c[0])
+def test_synth_index(index, case):
+    name, bpt, B, T, vocab, seed = case
+    toks = gi.edge_tokens(seed, B, T, vocab)
+    np.testing.assert_array_equal(toks, index[f"{name}/tokens"])
+    for side in ("left", "right"):
+        tab = gi.synth_ttb(seed + 1000, vocab, bpt, side)
+        padded = orc.tokens_to_bytes(toks, ttb_f32(tab))
+        np.testing.assert_array_equal(padded, index[f"{name}/{side}/padded"])
+        own = orc.pull_from_left if side == "left" else orc.pull_from_right
+        other = orc.pull_from_right if side == "left" else orc.pull_from_left
+        np.testing.assert_array_equal(own(padded, bpt, gi.PAD, gi.EOT), index[f"{name}/{side}/pulled"])
+        np.testing.assert_array_equal(other(padded, bpt, gi.PAD, gi.EOT), index[f"{name}/{side}/pulled_other"])
+
+
+@pytest.mark.parametrize("case", gi.RAW_INDEX_CASES, ids=lambda c: c[0])
+def test_raw_index(index, case):
+    name, bpt, B, Tr, seed = case
+    x = gi.raw_byte_tensor(seed, B, Tr, bpt)
+    np.testing.assert_array_equal(x, index[f"{name}/in"])
+    np.testing.assert_array_equal(orc.pull_from_left(x, bpt, gi.PAD, gi.EOT), index[f"{name}/left"])
+    np.testing.assert_array_equal(orc.pull_from_right(x, bpt, gi.PAD, gi.EOT), index[f"{name}/right"])
+
+
+def test_empty_and_bad_shape(index):
+    z = np.zeros((2, 0), dtype=np.int64)
+    assert orc.pull_from_left(z, 8, gi.PAD, gi.EOT).shape == index["empty/left"].shape == (2, 0)
+    assert orc.pull_from_right(z, 8, gi.PAD, gi.EOT).shape == index["empty/right"].shape == (2, 0)
+    with pytest.raises(AssertionError):  # data_creation.py:85,192
+        orc.pull_from_left(np.zeros((1, 12), dtype=np.int64), 8, gi.PAD, gi.EOT)
+    with pytest.raises(IndexError):
+        orc.tokens_to_bytes(np.array([[99]], dtype=np.int32), np.zeros((4, 8), dtype=np.float32))
+
+
+def test_make_embedding_quirk_row():
+    z = np.load(G / "make_embedding.npz")
+    tab = ttb_f32(gi.load_real_ttb8())
+    tab[gi.GPT2_VOCAB - 1] = z["eot_row_f32"]          # the random-normal row the reference left in place
+    np.testing.assert_array_equal(orc.tokens_to_bytes(z["tokens"], tab), z["padded"])
+
+
+def test_loader_slice_shift_and_create_batch():
+    z = np.load(G / "loader.npz")
+    bpt, vocab = 16, 512
+    tab = ttb_f32(gi.synth_ttb(3001, vocab, bpt, "left"))
+    tabr = ttb_f32(gi.synth_ttb(3001, vocab, bpt, "right"))
+    pos, batch, seq = int(z["pos"]), int(z["batch"]), int(z["seq"])
+    for world in (1, 2, 4):
+        for rank in range(world):
+            p = f"w{world}r{rank}"
+            toks_in, targets = orc.rank_slice_shift(z["data"], pos, batch, seq, rank, world)
+            np.testing.assert_array_equal(toks_in, z[f"{p}/toks_in"])
+            np.testing.assert_array_equal(targets, z[f"{p}/targets"])
+            # bytes: computed on the (rows, seq+1) slice, then the last token's slots dropped
+            full = np.concatenate([toks_in, targets[:, -1:]], axis=1)
+            padded = orc.tokens_to_bytes(full, tab)
+            pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+            np.testing.assert_array_equal(padded[:, :-bpt], z[f"{p}/bytes_padded_in"])
+            np.testing.assert_array_equal(pulled[:, :-bpt], z[f"{p}/bytes_pulled_in"])
+    full = orc.create_batch(z["create_batch/tokens"], bpt, gi.PAD, gi.EOT, tabr, tab)
+    np.testing.assert_array_equal(full, z["create_batch/full"])
+
+
+def test_mathblations_digits_and_mixin():
+    z = np.load(G / "mathblations_c1.npz")
+    np.testing.assert_array_equal(orc.tokens_to_digits(np.arange(1003), 3).reshape(1003, 3), z["digit_table"])
+    np.testing.assert_array_equal(orc.tokens_to_digits(z["all_tokens"], 3), z["all_digits"])
+    # inputs drop the last token / the last lf digits (data.py:169-175)
+    np.testing.assert_array_equal(z["all_tokens"][:, :-1], z["x_tokens"])
+    np.testing.assert_array_equal(z["all_digits"][:, :-3], z["x_digit_tokens"])
+    D = 256
+    Wt, Wd = gi.normal_table(601, 1003, D), gi.normal_table(602, 14, D)
+    Wf, bf = gi.linear_weight_bias(603, D, 4 * D)
+    kw = dict(mode="concat_linear", bpt=3, bytes_first=True)
+    x64 = orc.embed_mix(z["x_tokens"], z["x_digit_tokens"], None, Wt, Wd, weight=Wf, bias=bf, dtype=np.float64, **kw)
+    np.testing.assert_allclose(x64, z["concat/f64/x"], rtol=1e-12, atol=1e-12)
+    x32 = orc.embed_mix(z["x_tokens"], z["x_digit_tokens"], None, f32(Wt), f32(Wd), weight=f32(Wf), bias=f32(bf),
+                        dtype=np.float32, **kw)
+    np.testing.assert_allclose(x32, z["concat/f32/x"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(x32, z["concat/f64/x"], rtol=2e-6, atol=2e-6)
+
+
+SCALED = [("small", 97, 32, 8, 64, 8, 2, 16, 401), ("c2dims", 512, 256, 32, 768, 16, 1, 48, 402)]
+
+
+@pytest.mark.parametrize("case", SCALED, ids=lambda c: c[0])
+def test_scaled_pretrain_float(case):
+    name, Vt, Dt, Db, Dm, bpt, B, T, seed = case
+    z = np.load(G / "float_scaled.npz")
+    toks = gi.edge_tokens(seed, B, T, Vt, eot_p=0.08)
+    np.testing.assert_array_equal(toks, z[f"{name}/tokens"])
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    padded = orc.tokens_to_bytes(toks, ttb_f32(tab))
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    np.testing.assert_array_equal(padded, z[f"{name}/padded"])
+    np.testing.assert_array_equal(pulled, z[f"{name}/pulled"])
+    Et, Eb = gi.normal_table(seed + 1, Vt, Dt), gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db)
+    W = gi.casted_linear_weight(seed + 3, Dm, Dt + bpt * Db)
+    ids = dict(padded=(padded, None), pulled=(pulled, None), padded_and_pulled=(padded, pulled))
+    for mode, (ia, ib) in ids.items():
+        if f"{name}/{mode}/f64/x" not in z:
+            continue
+        kw = dict(mode="concat_linear", bpt=bpt, norm_tok=True, norm_byte=True, norm_out=True, return_seam=True)
+        x, te, be = orc.embed_mix(toks, ia, ib, Et, Eb, weight=W, dtype=np.float64, **kw)
+        np.testing.assert_allclose(x, z[f"{name}/{mode}/f64/x"], rtol=1e-12, atol=1e-12)
+        x32, te32, be32 = orc.embed_mix(toks, ia, ib, f32(Et), f32(Eb), weight=f32(W), dtype=np.float32, **kw)
+        np.testing.assert_allclose(x32, z[f"{name}/{mode}/f32/x"], rtol=2e-5, atol=2e-5)
+        np.testing.assert_allclose(x32, z[f"{name}/{mode}/f64/x"], rtol=2e-6, atol=2e-6)
+        if name == "small":
+            np.testing.assert_allclose(te, z[f"{name}/{mode}/f64/tok_embs"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(be, z[f"{name}/{mode}/f64/byte_embs"], rtol=1e-12, atol=1e-12)
+            # the seam tensors are gather + rms-norm only: the 1e-6 bar applies
+            np.testing.assert_allclose(te32, z[f"{name}/{mode}/f32/tok_embs"], rtol=1e-6, atol=1e-6)
+            np.testing.assert_allclose(be32, z[f"{name}/{mode}/f32/byte_embs"], rtol=1e-6, atol=1e-6)
+    x = orc.embed_mix(toks, None, None, Et, None, mode="noop", bpt=bpt, norm_tok=True, dtype=np.float64)
+    np.testing.assert_allclose(x, z[f"{name}/noop/f64/x"], rtol=1e-12, atol=1e-12)
+    x32 = orc.embed_mix(toks, None, None, f32(Et), None, mode="noop", bpt=bpt, norm_tok=True, dtype=np.float32)
+    np.testing.assert_allclose(x32, z[f"{name}/noop/f32/x"], rtol=1e-6, atol=1e-6)
+
+
+SUMC = [("small", 97, 64, 8, 8, 40, 501), ("c2dims", 512, 768, 48, 16, 48, 502)]
+
+
+@pytest.mark.parametrize("case", SUMC, ids=lambda c: c[0])
+def test_sum_modes(case):
+    name, Vt, D, Db, bpt, T, seed = case
+    z = np.load(G / "sum_modes.npz")
+    toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, ttb_f32(tab)), bpt, gi.PAD, gi.EOT)
+    np.testing.assert_array_equal(pulled, z[f"{name}/pulled"])
+    Et, Eb = gi.normal_table(seed + 1, Vt, D), gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db)
+    s_tok, s_byte = z[f"{name}/scales"]
+    variants = dict(
+        r71=dict(norm_out=True),
+        r71041=dict(norm_tok=True, norm_byte=True, norm_out=True, scale_tok=s_tok, scale_byte=s_byte),
+        r71081=dict(norm_tok=True, norm_byte=True, scale_tok=s_tok, scale_byte=s_byte),
+    )
+    for v, kw in variants.items():
+        x = orc.embed_mix(toks, pulled, None, Et, Eb, mode="sum", bpt=bpt, dtype=np.float64, **kw)
+        np.testing.assert_allclose(x, z[f"{name}/{v}/f64"], rtol=1e-12, atol=1e-12)
+        x32 = orc.embed_mix(toks, pulled, None, f32(Et), f32(Eb), mode="sum", bpt=bpt, dtype=np.float32, **kw)
+        # headline bar: fp32 mixed embeddings within 1e-6 of the reference CPU path
+        np.testing.assert_allclose(x32, z[f"{name}/{v}/f32"], rtol=1e-6, atol=1e-6)
