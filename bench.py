@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the fused mixture-of-tokenizers embedding front-end on MI355X.
+
+One "step" = one pass of the hot path over one synthetic batch: tokens (int32, resident in HBM)
+-> token->byte table gather -> pull-from-left -> token/byte embedding gathers -> sum -> rms-norm
+-> x (fp32), i.e. ONE launch of mot_embed_mix_fwd (include/mot.h).  Default workload is
+BASELINE.json configs[3] at one GPU: B x T = 256 x 2048, GPT-2 vocab 50257, bpt 16, d_model 768
+(byte dim 48), FineWeb-shaped ids.  With --gpus N every rank runs the same
+per-GPU batch on its own shard of rows (weak scaling; the path has no data-path collective),
+and the only RCCL traffic is the counter all-reduce after the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch / average
+launch duration measured with HIP events on the launch stream; `cpu_baseline` = the CPU oracle
+(a C/OpenMP port of the reference path) timed on this host on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+sys.path.insert(0, str(REPO / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6300
+
+WORKLOADS = {
+    # name: (B, T, vocab, bpt, d_model, byte_dim, byte_vocab, mode)
+    "c4": (256, 2048, 50257, 16, 768, 48, 458, "sum"),     # headline: BASELINE configs[3]
+    "c2": (64, 1024, 50257, 16, 768, 48, 458, "sum"),      # configs[1]
+    "c5": (64, 8192, 128256, 8, 2048, 2048, 132, "mean"),  # configs[4] shape family, quarter batch
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--ids", default="fused", choices=["fused", "given"],
+                    help="fused: byte ids produced inside the kernel; given: int64 ids precomputed (module-level path)")
+    ap.add_argument("--uniform-ids", action="store_true", help="uniform token ids (no-reuse worst case)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def make_inputs(wl, device, seed, uniform):
+    import golden_inputs as gi
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    g = torch.Generator(device=device).manual_seed(seed)
+    tok_table = torch.randn((vocab, D), generator=g, device=device, dtype=torch.float32)
+    byte_table = torch.randn((Vb, Db), generator=g, device=device, dtype=torch.float32)
+    if mode == "sum":
+        try:
+            tab = gi.widen_left_pad(gi.load_real_ttb8(), bpt)     # real GPT-2 token->char table (data fixture)
+            ttb_kind = "gpt2 ttb_8_left_pad widened to 16"
+        except FileNotFoundError:
+            tab = gi.synth_ttb(5, vocab, bpt, "left")
+            ttb_kind = "synthetic"
+        toks = gi.fineweb_like_tokens(seed, B, T, vocab=vocab, uniform=uniform)
+        return dict(toks=toks, tab=tab, tok_table=tok_table, byte_table=byte_table, ttb_kind=ttb_kind)
+    rs = np.random.RandomState(seed)
+    toks = rs.randint(0, vocab, size=(B, T)).astype(np.int32)
+    chars = rs.randint(0, Vb, size=(B, T * bpt)).astype(np.int64)
+    return dict(toks=toks, chars=chars, tok_table=tok_table, byte_table=byte_table, ttb_kind="n/a")
+
+
+def algorithmic_bytes_per_token(wl, ids_mode):
+    """fully fused R = 4 + 2*bpt + e*Dt, W = e*Dm; module-level path reads int64 ids."""
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    e = 4
+    if mode == "sum":
+        r = 4 + (2 * bpt if ids_mode == "fused" else 8 * bpt) + e * D
+    else:
+        r = 4 + 8 * bpt + e * D
+    return r + e * D
+
+
+def cpu_baseline(wl, inp, seconds):
+    """The oracle (oracle/mot_oracle.c, OpenMP) on this host: tokens_to_bytes + pull_from_left +
+    gather/sum/rms-norm in fp32 on rows of the same workload, repeated for ~`seconds`."""
+    from oracle import oracle as orc
+    import golden_inputs as gi
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    cores = len(os.sched_getaffinity(0))
+    orc.set_threads(cores)
+    Et, Eb = inp["tok_table"].cpu().numpy(), inp["byte_table"].cpu().numpy()
+    rows = min(B, 32)
+    toks = inp["toks"][:rows]
+
+    def once():
+        if mode == "sum":
+            padded = orc.tokens_to_bytes(toks, inp["tab"].astype(np.float32))
+            pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+            orc.embed_mix(toks, pulled, None, Et, Eb, mode="sum", bpt=bpt, dtype=np.float32, norm_out=True)
+        else:
+            orc.embed_mix(toks, inp["chars"][:rows], None, Et, Eb, mode="mean", bpt=bpt, dtype=np.float32)
+
+    once()
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        once()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or reps >= 200:
+            break
+    return dict(value=rows * T * reps / el, unit="tokens/s", cores=cores, kind="port",
+                sample=f"{reps} passes over {rows}x{T} tokens of the same workload in {el:.1f} s "
+                       f"(oracle/mot_oracle.c, fp32, OpenMP {cores} threads)")
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import mixture_of_tokenizers_amd as mot
+    wl = args.workload
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    inp = make_inputs(wl, device, seed=12345 + rank, uniform=args.uniform_ids)   # loader default seed, train_gpt.py:661
+    toks = torch.from_numpy(inp["toks"]).to(device)
+    out = torch.empty((B, T, D), dtype=torch.float32, device=device)
+    counters = torch.zeros(4, dtype=torch.int64, device=device)
+    if mode == "sum":
+        tab = torch.from_numpy(inp["tab"]).to(device)
+        if args.ids == "fused":
+            def step(cnt=None):
+                mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="sum", bpt=bpt, ttb=tab, pull="left",
+                              norm_out=True, out=out, counters=cnt)
+        else:
+            from mixture_of_tokenizers_amd import data_creation as dc
+            ids = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
+
+            def step(cnt=None):
+                mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="sum", bpt=bpt, ids_a=ids, norm_out=True,
+                              out=out, counters=cnt)
+    else:
+        chars = torch.from_numpy(inp["chars"]).to(device)
+        lt, lc = torch.tensor(1.0, device=device), torch.tensor(0.5, device=device)
+
+        def step(cnt=None):
+            mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="mean", bpt=bpt, ids_a=chars, scale_tok=lt,
+                          scale_byte=lc, out=out, counters=cnt)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    step(counters)                                          # statistics pass, outside the timed region
+    torch.cuda.synchronize()
+    mot.check_status()
+
+    tokens_per_step = B * T
+    if world > 1:
+        import torch.distributed as dist
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)     # the path's only collective: <= 64 B over RCCL/xGMI
+        kms = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(tmax.item()), float(kms.item())
+    total_tokens = tokens_per_step * world * args.steps
+
+    if rank == 0:
+        bpt_alg = algorithmic_bytes_per_token(wl, args.ids)
+        launch_bytes = bpt_alg * tokens_per_step
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = REPO / "profiles" / "traffic.json"
+        if tfile.exists():
+            try:
+                traffic = json.loads(tfile.read_text()).get(f"{wl}_{args.ids}")
+            except Exception:
+                traffic = None
+        c = counters.tolist()
+        res = {
+            "metric": "mixed-embed tokens/sec at BxT=256x2048; achieved HBM GB/s vs peak",
+            "value": total_tokens / elapsed,
+            "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{wl}: BxT={B}x{T} per GPU, vocab {vocab}, bpt {bpt}, d_model {D}, byte_dim {Db}, "
+                                   f"mode {mode}+rmsnorm, ids {args.ids}, token ids "
+                                   f"{'uniform' if args.uniform_ids else 'FineWeb-shaped (u^3 skew, EOT p=1/700)'}, "
+                                   f"ttb {inp['ttb_kind']}",
+                       "global_tokens_per_step": tokens_per_step * world, "parallelism": f"batch-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "embed_mix_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_token": bpt_alg, "tokens_per_launch": tokens_per_step},
+            "byte_stats": {"tokens": c[0], "slots": c[1], "pads_before": c[2], "pads_after": c[3],
+                           "mean_valid_per_token": (c[1] - c[2]) / max(c[0], 1),
+                           "pulled_fill": (c[2] - c[3]) / max(c[1], 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(wl, inp, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

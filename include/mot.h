@@ -1,0 +1,198 @@
+/*
+ * mot.h -- C ABI of libmot_hip.so: the MI355X (gfx950) implementation of the
+ * mixture-of-tokenizers embedding front-end.
+ *
+ * The reference (snimu/mixture-of-tokenizers) exposes this path as Python functions and
+ * nn.Module.forward() calls, not as an FFI; each entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout).  Host bindings live in
+ * mixture-of-tokenizers_amd/_capi.py (ctypes); INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless a comment says "host"
+ *   - the caller owns all buffers (inputs, outputs, workspace); the library allocates nothing
+ *     and keeps no state between calls, so calls are re-entrant and hipGraph-capturable
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and never synchronises the host
+ *   - return value: MOT_OK or a negative MotStatus; mot_last_error() gives a thread-local
+ *     message for the last failing call on this thread
+ *   - byte tensors use the reference's layout: (B, T*bpt) row-major, token-major / slot-minor
+ */
+#ifndef MOT_H_
+#define MOT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOT_ABI_VERSION 1
+#define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
+
+typedef void *mot_stream_t; /* hipStream_t */
+
+typedef enum MotStatus {
+    MOT_OK = 0,
+    MOT_EINVAL = -1,       /* null pointer / bad enum / bad struct_size                     */
+    MOT_ESHAPE = -2,       /* shape the reference asserts on (e.g. T % bytes_per_token)     */
+    MOT_EUNSUPPORTED = -3, /* valid request this build has no kernel for                    */
+    MOT_EHIP = -4,         /* HIP runtime error (launch failure, no device)                 */
+    MOT_EWORKSPACE = -5    /* workspace missing or smaller than mot_embed_mix_workspace_bytes */
+} MotStatus;
+
+/* Bits of the optional device status word (`status` arguments / MotEmbedMixDesc.status).
+ * Kernels OR them in with atomics; out-of-range ids are clamped to row 0 so that a bad id can
+ * never fault -- the host shim turns a non-zero word into the reference's IndexError. */
+#define MOT_STATUS_TOKEN_OOR 1u /* token id outside [0, tok_rows) / [0, ttb_rows) */
+#define MOT_STATUS_BYTE_OOR 2u  /* byte id outside [0, byte_rows)                 */
+
+typedef enum MotPullDir {
+    MOT_PULL_NONE = 0,
+    MOT_PULL_LEFT = 1, /* pull_from_left : window ends at the token, right-aligned  */
+    MOT_PULL_RIGHT = 2 /* pull_from_right: window starts at the token, left-aligned */
+} MotPullDir;
+
+typedef enum MotMixMode {
+    MOT_MIX_NOOP = 0,         /* x = tok part            (train_gpt.py:342-348, 421-427)            */
+    MOT_MIX_SUM = 1,          /* x = a + concat_k b_k    (modded-nanogpt/runs/71_*.py:227-230)      */
+    MOT_MIX_MEAN = 2,         /* x = a + mean_k b_k      (inference/inference.py:266-267)           */
+    MOT_MIX_CONCAT_LINEAR = 3 /* x = W.cat(a, b_*) + bias (train_gpt.py:430-443; model.py:256-268)  */
+} MotMixMode;
+
+typedef enum MotIdSource {
+    MOT_IDS_NONE = 0,     /* MOT_MIX_NOOP                                                       */
+    MOT_IDS_FROM_TTB = 1, /* fully fused: tokens -> ttb gather -> pull, byte ids never leave LDS */
+    MOT_IDS_GIVEN = 2     /* ids_a (and ids_b) precomputed int64, as the reference loader emits  */
+} MotIdSource;
+
+typedef enum MotDType { MOT_F32 = 0 } MotDType;
+
+int mot_version(void);                /* MOT_ABI_VERSION the library was built with */
+const char *mot_last_error(void);     /* host string, thread-local, never NULL      */
+const char *mot_build_info(void);     /* host string: arch, compiler, build flags   */
+
+/*
+ * Replaces tokens_to_bytes(tokens, emb)           scaled-pre-train/data_creation.py:61-67
+ * (and the table built by make_embedding, :51-58, which the host keeps as an integer table).
+ *   tokens  int32 [n_tokens]         ttb  int16|int32 [ttb_rows, bpt] (ttb_elem_bytes = 2|4)
+ *   out     int64 [n_tokens*bpt]     status optional
+ */
+int mot_tokens_to_bytes(const int32_t *tokens, int64_t n_tokens, const void *ttb,
+                        int ttb_elem_bytes, int64_t ttb_rows, int bpt, int64_t *out,
+                        uint32_t *status, mot_stream_t stream);
+
+/*
+ * Replaces pull_from_left / pull_from_right(byte_tensor, bytes_per_token, pad_byte, eot_byte)
+ *                                                 scaled-pre-train/data_creation.py:179-305 / 71-176
+ *   in, out  int64 [B, T] with T = tokens_per_row*bpt; any int64 values are legal
+ *   T == 0 is a no-op (data_creation.py:82-83,190); T % bpt != 0 -> MOT_ESHAPE (:85,192)
+ *   in == out is NOT allowed.
+ */
+int mot_pull_bytes(const int64_t *in, int64_t *out, int64_t B, int64_t T, int bpt,
+                   int64_t pad_byte, int64_t eot_byte, int dir /* MotPullDir */,
+                   mot_stream_t stream);
+
+/*
+ * Replaces create_batch(tokens, bpt, pad, eot, ttb_right, ttb_left)
+ *                                                 scaled-pre-train/data_creation.py:308-330
+ *   out int64 [B, T, 1 + 4*bpt] = [token | left-padded | pulled-from-left | right-padded |
+ *   pulled-from-right]; one fused launch, no intermediate tensors.
+ */
+int mot_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *ttb_left,
+                     const void *ttb_right, int ttb_elem_bytes, int64_t ttb_rows, int bpt,
+                     int64_t pad_byte, int64_t eot_byte, int64_t *out, uint32_t *status,
+                     mot_stream_t stream);
+
+/*
+ * Replaces emb(ids) / norm(emb(ids)) / norm(emb(ids_a) + emb(ids_b)) when the caller wants the
+ * tensors at the FlexibleEmbedding seam materialised
+ *                                                 scaled-pre-train/train_gpt.py:342-379, 172-173
+ *   ids int64|int32 [n] (ids_elem_bytes 8|4), ids_b optional; table f32 [rows, dim];
+ *   out f32 [n, dim]; rms_norm: x * rsqrt(mean(x^2) + eps), eps <= 0 -> FLT_EPSILON
+ *   (F.rms_norm eps=None); scale optional device scalar.
+ */
+int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, int64_t n,
+                    const float *table, int64_t rows, int dim, int rms_norm, float eps,
+                    const float *scale, float *out, uint32_t *status, mot_stream_t stream);
+
+/*
+ * The fused front-end.  Replaces, in ONE launch (plus a 458-row prologue when norm_byte is set):
+ *   FlexibleEmbedding.forward + ByteMixin.forward  scaled-pre-train/train_gpt.py:327-379, 421-480
+ *   (call site train_gpt.py:605-606), optionally with the loader's tokens_to_bytes + pull
+ *   (train_gpt.py:686-728) folded in;
+ *   GPT.wte / GPT.dte / digit_mixin                mathblations/model.py:256-268, 304-306, 323-327;
+ *   embed_tokens / embed_bytes / mixin_bytes       modded-nanogpt/runs/71_*.py:227-230, 312-314
+ *   (and the per-embedding-norm / lambda variants runs/71041_*.py:311-313, runs/71081_*.py:302-315).
+ *
+ * Per token n of row-major (B, T):
+ *   a   = tok_table[tokens[n]];            if norm_tok:  a = rms_norm(a);    a *= *scale_tok
+ *   b_k = byte_table[idsA[n,k]] (+ byte_table[idsB[n,k]]);
+ *                                          if norm_byte: b_k = rms_norm(b_k); b_k *= *scale_byte
+ *   x   = mix(a, b_0..b_{bpt-1}) per `mode`;  if norm_out: x = rms_norm(x)
+ * where idsA/idsB come from `id_source`:
+ *   MOT_IDS_FROM_TTB: padded = ttb[tokens[n]], pulled = pull(padded) along each row;
+ *       idsA = pulled (or padded when pull_dir == NONE); idsB = padded iff add_padded
+ *   MOT_IDS_GIVEN:    idsA = ids_a, idsB = ids_b (NULL = none)
+ */
+typedef struct MotEmbedMixDesc {
+    uint32_t struct_size; /* sizeof(MotEmbedMixDesc), checked */
+    int32_t dtype;        /* MotDType of tables / weight / out */
+
+    /* problem */
+    int64_t n_rows;         /* B */
+    int64_t tokens_per_row; /* T (tokens, not byte slots) */
+    int32_t bpt;            /* byte slots per token; 0 for MOT_MIX_NOOP */
+    int32_t mode;           /* MotMixMode */
+
+    /* ids */
+    const int32_t *tokens; /* [B, T] */
+    int32_t id_source;     /* MotIdSource */
+    int32_t pull_dir;      /* MotPullDir          (FROM_TTB) */
+    const void *ttb;       /* [ttb_rows, bpt]     (FROM_TTB) */
+    int64_t ttb_rows;
+    int32_t ttb_elem_bytes; /* 2 | 4 */
+    int32_t add_padded;     /* FROM_TTB: idsB = unpulled row (train_gpt.py:371-379) */
+    int32_t pad_byte, eot_byte;
+    const int64_t *ids_a; /* [B, T*bpt]          (GIVEN) */
+    const int64_t *ids_b; /* optional            (GIVEN) */
+
+    /* tables */
+    const void *tok_table; /* [tok_rows, tok_dim], contiguous */
+    int64_t tok_rows;
+    int32_t tok_dim;
+    int32_t byte_dim;
+    const void *byte_table; /* [byte_rows, byte_dim] */
+    int64_t byte_rows;
+
+    /* mixing */
+    int32_t model_dim;   /* output columns; SUM/MEAN/NOOP require == tok_dim */
+    int32_t bytes_first; /* CONCAT_LINEAR: 0 = [a, b_*] (train_gpt.py:443), 1 = [b_*, a] (model.py:267) */
+    const void *weight;  /* CONCAT_LINEAR: [model_dim, tok_dim + bpt*byte_dim] row-major (nn.Linear) */
+    const void *bias;    /* optional [model_dim] */
+    int32_t norm_tok, norm_byte, norm_out;
+    float eps;                /* <= 0 -> FLT_EPSILON (torch.finfo(float32).eps) */
+    const float *scale_tok;   /* optional device scalar */
+    const float *scale_byte;  /* optional device scalar */
+
+    /* outputs */
+    void *out;               /* [B, T, model_dim] */
+    int64_t *out_ids_padded; /* optional [B, T*bpt]: what tokens_to_bytes would return (FROM_TTB) */
+    int64_t *out_ids_pulled; /* optional [B, T*bpt]: what pull_from_* would return    (FROM_TTB) */
+    int64_t *counters;       /* optional int64[4], atomically incremented: tokens, byte slots,
+                                pads before the pull, pads after (runs/79_*.py:484-488)        */
+    uint32_t *status;        /* optional device word, see MOT_STATUS_* */
+
+    /* scratch */
+    void *workspace; /* >= mot_embed_mix_workspace_bytes(desc); may be NULL when that is 0 */
+    size_t workspace_bytes;
+} MotEmbedMixDesc;
+
+size_t mot_embed_mix_desc_size(void); /* sizeof(MotEmbedMixDesc) in this build, for bindings */
+size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc /* host */);
+int mot_embed_mix_fwd(const MotEmbedMixDesc *desc /* host */, mot_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOT_H_ */

@@ -1,0 +1,163 @@
+"""ctypes binding of libmot_hip.so (include/mot.h) -- the only place the C ABI is called from.
+
+The library is hand-written HIP for gfx950; there is NO CPU or PyTorch fallback in this
+package: if the shared object is missing, importing this module raises, and every wrapper
+refuses tensors that are not on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libmot_hip.so"
+
+# ---- enums of include/mot.h
+MOT_OK, MOT_EINVAL, MOT_ESHAPE, MOT_EUNSUPPORTED, MOT_EHIP, MOT_EWORKSPACE = 0, -1, -2, -3, -4, -5
+STATUS_TOKEN_OOR, STATUS_BYTE_OOR = 1, 2
+PULL_NONE, PULL_LEFT, PULL_RIGHT = 0, 1, 2
+MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
+IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
+F32 = 0
+MAX_BPT = 64
+ABI_VERSION = 1
+
+EXPORTS = (
+    "mot_version", "mot_last_error", "mot_build_info", "mot_tokens_to_bytes", "mot_pull_bytes",
+    "mot_create_batch", "mot_gather_rows", "mot_embed_mix_desc_size", "mot_embed_mix_workspace_bytes",
+    "mot_embed_mix_fwd",
+)
+
+
+class MotEmbedMixDesc(C.Structure):
+    """Field-for-field mirror of struct MotEmbedMixDesc (include/mot.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("dtype", C.c_int32),
+        ("n_rows", C.c_int64), ("tokens_per_row", C.c_int64), ("bpt", C.c_int32), ("mode", C.c_int32),
+        ("tokens", C.c_void_p), ("id_source", C.c_int32), ("pull_dir", C.c_int32),
+        ("ttb", C.c_void_p), ("ttb_rows", C.c_int64), ("ttb_elem_bytes", C.c_int32), ("add_padded", C.c_int32),
+        ("pad_byte", C.c_int32), ("eot_byte", C.c_int32),
+        ("ids_a", C.c_void_p), ("ids_b", C.c_void_p),
+        ("tok_table", C.c_void_p), ("tok_rows", C.c_int64), ("tok_dim", C.c_int32), ("byte_dim", C.c_int32),
+        ("byte_table", C.c_void_p), ("byte_rows", C.c_int64),
+        ("model_dim", C.c_int32), ("bytes_first", C.c_int32), ("weight", C.c_void_p), ("bias", C.c_void_p),
+        ("norm_tok", C.c_int32), ("norm_byte", C.c_int32), ("norm_out", C.c_int32), ("eps", C.c_float),
+        ("scale_tok", C.c_void_p), ("scale_byte", C.c_void_p),
+        ("out", C.c_void_p), ("out_ids_padded", C.c_void_p), ("out_ids_pulled", C.c_void_p),
+        ("counters", C.c_void_p), ("status", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+def _load() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` (or `make -C "
+            f"{_HERE / 'csrc'}`).  This package has no fallback path.")
+    lib = C.CDLL(str(LIB_PATH))
+    vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+    lib.mot_version.restype = C.c_int
+    lib.mot_last_error.restype = C.c_char_p
+    lib.mot_build_info.restype = C.c_char_p
+    lib.mot_tokens_to_bytes.argtypes = [vp, i64, vp, i32, i64, i32, vp, vp, vp]
+    lib.mot_pull_bytes.argtypes = [vp, vp, i64, i64, i32, i64, i64, i32, vp]
+    lib.mot_create_batch.argtypes = [vp, i64, i64, vp, vp, i32, i64, i32, i64, i64, vp, vp, vp]
+    lib.mot_gather_rows.argtypes = [vp, vp, i32, i64, vp, i64, i32, i32, f32, vp, vp, vp, vp]
+    lib.mot_embed_mix_desc_size.restype = C.c_size_t
+    lib.mot_embed_mix_workspace_bytes.restype = C.c_size_t
+    lib.mot_embed_mix_workspace_bytes.argtypes = [C.POINTER(MotEmbedMixDesc)]
+    lib.mot_embed_mix_fwd.argtypes = [C.POINTER(MotEmbedMixDesc), vp]
+    for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_gather_rows", "mot_embed_mix_fwd"):
+        getattr(lib, name).restype = C.c_int
+    if lib.mot_version() != ABI_VERSION:
+        raise ImportError(f"libmot_hip.so ABI {lib.mot_version()} != binding ABI {ABI_VERSION}")
+    if lib.mot_embed_mix_desc_size() != C.sizeof(MotEmbedMixDesc):
+        raise ImportError("MotEmbedMixDesc layout mismatch between include/mot.h and _capi.py")
+    return lib
+
+
+lib = _load()
+
+_EXC = {MOT_EINVAL: ValueError, MOT_ESHAPE: AssertionError, MOT_EUNSUPPORTED: NotImplementedError,
+        MOT_EHIP: RuntimeError, MOT_EWORKSPACE: RuntimeError}
+
+
+def check(rc: int) -> None:
+    """Map a MotStatus to the exception type the reference would raise at that point."""
+    if rc != MOT_OK:
+        raise _EXC.get(rc, RuntimeError)(lib.mot_last_error().decode())
+
+
+def build_info() -> str:
+    return lib.mot_build_info().decode()
+
+
+# ----------------------------------------------------------------------------------------------
+# device-side status word: out-of-range ids are flagged, not faulted on (kernels clamp to row 0)
+# ----------------------------------------------------------------------------------------------
+_status_words: dict[int, torch.Tensor] = {}
+_debug_ids = os.environ.get("MOT_DEBUG_IDS", "0") not in ("0", "")
+
+
+def set_debug_ids(on: bool) -> None:
+    """When on, every call synchronises and raises IndexError on an out-of-range id, like
+    nn.Embedding does on CPU.  Off (default): call check_status() when convenient."""
+    global _debug_ids
+    _debug_ids = bool(on)
+
+
+def status_word(device: torch.device) -> torch.Tensor:
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    w = _status_words.get(idx)
+    if w is None:
+        w = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+        _status_words[idx] = w
+    return w
+
+
+def check_status(device=None) -> None:
+    """Synchronising check of the status word(s); raises IndexError as nn.Embedding would."""
+    for idx, w in list(_status_words.items()):
+        if device is not None and torch.device(device).index not in (None, idx):
+            continue
+        v = int(w.item())
+        if v:
+            w.zero_()
+            what = [n for bit, n in ((STATUS_TOKEN_OOR, "token id"), (STATUS_BYTE_OOR, "byte id")) if v & bit]
+            raise IndexError(f"index out of range in self ({' and '.join(what)} out of range)")
+
+
+def after_call(device: torch.device) -> None:
+    if _debug_ids:
+        check_status(device)
+
+
+# ----------------------------------------------------------------------------------------------
+# tensor plumbing
+# ----------------------------------------------------------------------------------------------
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "mixture-of-tokenizers_amd runs on a HIP device only (got a CPU tensor); "
+                "there is deliberately no CPU path in this package")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"tensors on different devices: {dev} vs {t.device}")
+    assert dev is not None
+    return dev
+
+
+def ptr(t) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,167 @@
+// mot_capi.hip -- the extern "C" surface of libmot_hip.so (see include/mot.h): argument
+// validation, error strings, dispatch to the kernel launchers.  No allocation, no host sync.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "mot_internal.hpp"
+
+namespace mot {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(MOT_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return MOT_OK;
+}
+
+static int check_bpt(const char *fn, int bpt) {
+    if (bpt < 1 || bpt > MOT_MAX_BPT) return set_error(MOT_EUNSUPPORTED, "%s: bytes_per_token %d outside [1, %d]", fn, bpt, MOT_MAX_BPT);
+    return MOT_OK;
+}
+
+static int validate_embed_mix(const MotEmbedMixDesc *d) {
+    if (!d) return set_error(MOT_EINVAL, "embed_mix: null descriptor");
+    if (d->struct_size != sizeof(MotEmbedMixDesc))
+        return set_error(MOT_EINVAL, "embed_mix: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(MotEmbedMixDesc));
+    if (d->dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "embed_mix: dtype %d (only MOT_F32 is built)", d->dtype);
+    if (d->n_rows < 0 || d->tokens_per_row < 0) return set_error(MOT_ESHAPE, "embed_mix: negative shape");
+    if (d->mode < MOT_MIX_NOOP || d->mode > MOT_MIX_CONCAT_LINEAR) return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d->mode);
+    if (!d->tokens || !d->tok_table || !d->out) return set_error(MOT_EINVAL, "embed_mix: tokens/tok_table/out must be non-null");
+    if (d->tok_rows <= 0 || d->tok_dim <= 0 || d->model_dim <= 0) return set_error(MOT_ESHAPE, "embed_mix: empty token table");
+    if (d->tokens_per_row * (int64_t)(d->bpt > 0 ? d->bpt : 1) > 0x7fffffffLL)
+        return set_error(MOT_EUNSUPPORTED, "embed_mix: T*bpt exceeds 2^31");
+    if (d->mode != MOT_MIX_NOOP) {
+        int rc = check_bpt("embed_mix", d->bpt);
+        if (rc) return rc;
+        if (!d->byte_table || d->byte_rows <= 0 || d->byte_dim <= 0) return set_error(MOT_EINVAL, "embed_mix: byte table missing");
+        if (d->id_source == MOT_IDS_FROM_TTB) {
+            if (!d->ttb || d->ttb_rows <= 0) return set_error(MOT_EINVAL, "embed_mix: ttb missing");
+            if (d->ttb_elem_bytes != 2 && d->ttb_elem_bytes != 4) return set_error(MOT_EINVAL, "embed_mix: ttb_elem_bytes must be 2 or 4");
+            if (d->pull_dir < MOT_PULL_NONE || d->pull_dir > MOT_PULL_RIGHT) return set_error(MOT_EINVAL, "embed_mix: bad pull_dir %d", d->pull_dir);
+        } else if (d->id_source == MOT_IDS_GIVEN) {
+            if (!d->ids_a) return set_error(MOT_EINVAL, "embed_mix: ids_a missing");
+            if (d->out_ids_padded || d->out_ids_pulled) return set_error(MOT_EINVAL, "embed_mix: out_ids_* need MOT_IDS_FROM_TTB");
+        } else {
+            return set_error(MOT_EINVAL, "embed_mix: bad id_source %d", d->id_source);
+        }
+    }
+    const bool dual = d->mode != MOT_MIX_NOOP && (d->id_source == MOT_IDS_FROM_TTB ? d->add_padded != 0 : d->ids_b != nullptr);
+    switch (d->mode) {
+        case MOT_MIX_NOOP:
+            if (d->model_dim != d->tok_dim) return set_error(MOT_ESHAPE, "embed_mix noop: model_dim %d != tok_dim %d", d->model_dim, d->tok_dim);
+            break;
+        case MOT_MIX_SUM:
+            if (d->bpt * d->byte_dim != d->tok_dim || d->model_dim != d->tok_dim)
+                return set_error(MOT_ESHAPE, "embed_mix sum: need bpt*byte_dim == tok_dim == model_dim (got %d*%d, %d, %d)", d->bpt,
+                                 d->byte_dim, d->tok_dim, d->model_dim);
+            break;
+        case MOT_MIX_MEAN:
+            if (d->byte_dim != d->tok_dim || d->model_dim != d->tok_dim)
+                return set_error(MOT_ESHAPE, "embed_mix mean: need byte_dim == tok_dim == model_dim");
+            break;
+        case MOT_MIX_CONCAT_LINEAR:
+            if (!d->weight) return set_error(MOT_EINVAL, "embed_mix concat_linear: weight missing");
+            break;
+    }
+    if (d->mode != MOT_MIX_CONCAT_LINEAR) {
+        if ((d->tok_dim & 3) || (d->mode == MOT_MIX_SUM && (d->byte_dim & 3)))
+            return set_error(MOT_EUNSUPPORTED, "embed_mix: dims must be multiples of 4 floats (tok_dim %d, byte_dim %d)", d->tok_dim, d->byte_dim);
+        if (d->tok_dim > 2048) return set_error(MOT_EUNSUPPORTED, "embed_mix: model_dim %d > 2048 is not built", d->tok_dim);
+        if (dual && d->norm_byte)
+            return set_error(MOT_EUNSUPPORTED, "embed_mix: norm_byte over two id tensors is only built for CONCAT_LINEAR");
+    }
+    return MOT_OK;
+}
+
+}  // namespace mot
+
+using namespace mot;
+
+extern "C" {
+
+int mot_version(void) { return MOT_ABI_VERSION; }
+
+const char *mot_last_error(void) { return g_err; }
+
+const char *mot_build_info(void) {
+    return "libmot_hip gfx950 wave64 fp32 | hipcc " __VERSION__ " | built " __DATE__;
+}
+
+int mot_tokens_to_bytes(const int32_t *tokens, int64_t n_tokens, const void *ttb, int ttb_elem_bytes, int64_t ttb_rows,
+                        int bpt, int64_t *out, uint32_t *status, mot_stream_t stream) {
+    if (n_tokens < 0) return set_error(MOT_ESHAPE, "tokens_to_bytes: n_tokens < 0");
+    if (n_tokens == 0) return MOT_OK;
+    if (!tokens || !ttb || !out) return set_error(MOT_EINVAL, "tokens_to_bytes: null pointer");
+    if (ttb_elem_bytes != 2 && ttb_elem_bytes != 4) return set_error(MOT_EINVAL, "tokens_to_bytes: ttb_elem_bytes must be 2 or 4");
+    if (ttb_rows <= 0) return set_error(MOT_ESHAPE, "tokens_to_bytes: empty table");
+    int rc = check_bpt("tokens_to_bytes", bpt);
+    if (rc) return rc;
+    return launch_tokens_to_bytes(tokens, n_tokens, ttb, ttb_elem_bytes, ttb_rows, bpt, out, status, (hipStream_t)stream);
+}
+
+int mot_pull_bytes(const int64_t *in, int64_t *out, int64_t B, int64_t T, int bpt, int64_t pad_byte, int64_t eot_byte,
+                   int dir, mot_stream_t stream) {
+    if (B < 0 || T < 0) return set_error(MOT_ESHAPE, "pull_bytes: negative shape");
+    if (T == 0 || B == 0) return MOT_OK;  // data_creation.py:82-83, 190
+    int rc = check_bpt("pull_bytes", bpt);
+    if (rc) return rc;
+    if (T % bpt != 0) return set_error(MOT_ESHAPE, "pull_bytes: T must be divisible by bytes_per_token");  // :85, 192
+    if (!in || !out) return set_error(MOT_EINVAL, "pull_bytes: null pointer");
+    if (in == out) return set_error(MOT_EINVAL, "pull_bytes: in-place operation is not supported");
+    if (dir != MOT_PULL_LEFT && dir != MOT_PULL_RIGHT) return set_error(MOT_EINVAL, "pull_bytes: dir must be MOT_PULL_LEFT or MOT_PULL_RIGHT");
+    if (T > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "pull_bytes: row longer than 2^31 slots");
+    return launch_pull_bytes(in, out, B, T / bpt, bpt, pad_byte, eot_byte, dir, (hipStream_t)stream);
+}
+
+int mot_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *ttb_left, const void *ttb_right,
+                     int ttb_elem_bytes, int64_t ttb_rows, int bpt, int64_t pad_byte, int64_t eot_byte, int64_t *out,
+                     uint32_t *status, mot_stream_t stream) {
+    if (B < 0 || T < 0) return set_error(MOT_ESHAPE, "create_batch: negative shape");
+    if (B == 0 || T == 0) return MOT_OK;
+    if (!tokens || !ttb_left || !ttb_right || !out) return set_error(MOT_EINVAL, "create_batch: null pointer");
+    if (ttb_elem_bytes != 2 && ttb_elem_bytes != 4) return set_error(MOT_EINVAL, "create_batch: ttb_elem_bytes must be 2 or 4");
+    int rc = check_bpt("create_batch", bpt);
+    if (rc) return rc;
+    if (T * (int64_t)bpt > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "create_batch: row longer than 2^31 slots");
+    return launch_create_batch(tokens, B, T, ttb_left, ttb_right, ttb_elem_bytes, ttb_rows, bpt, (int32_t)pad_byte,
+                               (int32_t)eot_byte, out, status, (hipStream_t)stream);
+}
+
+int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, int64_t n, const float *table, int64_t rows,
+                    int dim, int rms_norm, float eps, const float *scale, float *out, uint32_t *status,
+                    mot_stream_t stream) {
+    if (n < 0) return set_error(MOT_ESHAPE, "gather_rows: n < 0");
+    if (n == 0) return MOT_OK;
+    if (!ids_a || !table || !out) return set_error(MOT_EINVAL, "gather_rows: null pointer");
+    if (ids_elem_bytes != 4 && ids_elem_bytes != 8) return set_error(MOT_EINVAL, "gather_rows: ids_elem_bytes must be 4 or 8");
+    if (rows <= 0 || dim <= 0) return set_error(MOT_ESHAPE, "gather_rows: empty table");
+    return launch_gather_rows(ids_a, ids_b, ids_elem_bytes, n, table, rows, dim, rms_norm, eps, scale, out, status,
+                              (hipStream_t)stream);
+}
+
+size_t mot_embed_mix_desc_size(void) { return sizeof(MotEmbedMixDesc); }
+
+size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc) {
+    if (!desc || desc->struct_size != sizeof(MotEmbedMixDesc)) return 0;
+    return embed_mix_workspace_bytes(*desc);
+}
+
+int mot_embed_mix_fwd(const MotEmbedMixDesc *desc, mot_stream_t stream) {
+    int rc = validate_embed_mix(desc);
+    if (rc) return rc;
+    if (desc->n_rows == 0 || desc->tokens_per_row == 0) return MOT_OK;
+    if (desc->mode == MOT_MIX_CONCAT_LINEAR) return launch_embed_mix_linear(*desc, (hipStream_t)stream);
+    return launch_embed_mix(*desc, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,447 @@
+// mot_embed.hip -- float path kernels (gfx950): the fused gather + mix forward for the
+// SUM / MEAN / NOOP modes, the seam gather (materialised FlexibleEmbedding outputs) and the
+// byte-table inverse-rms prologue.  fp32 throughout (the reference's CPU parity mode).
+//
+// Fused kernel, per tile of <= 256 tokens of one row (one 256-thread workgroup):
+//   phase 1  byte ids for the tile into LDS: token->byte-table gather + pull (mot_tile.hpp), or a
+//            coalesced copy of precomputed int64 ids.  Byte ids never touch HBM.
+//   phase 2  one wave per token, U tokens in flight per wave: the token row is read with
+//            16 B/lane coalesced loads (lane l owns float4 chunks l, l+64, ...), the byte rows
+//            that line up with those chunks come from the (L2-resident, <= 1.4 MB) byte table,
+//            rms-norm reductions are wave shuffles, the mixed row is written once with
+//            non-temporal 16 B stores.  Algorithmic traffic: 4 + 2*bpt + 4*Dt B read and
+//            4*Dm B written per token; HBM-bound.
+#include <float.h>
+
+#include "mot_internal.hpp"
+#include "mot_tile.hpp"
+
+namespace mot {
+
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+struct MixArgs {
+    // ids
+    const int32_t *tokens;
+    int64_t T;  // tokens per row
+    int bpt;
+    int id_source, pull_dir;
+    const void *ttb;
+    int64_t ttb_rows;
+    int ttb_elem;
+    int add_padded;
+    int32_t pad, eot;
+    const int64_t *ids_a, *ids_b;
+    // tables
+    const float *tok_table;
+    int64_t tok_rows;
+    int Dt;
+    const float *byte_table;
+    int64_t byte_rows;
+    int Db;
+    int norm_tok, norm_byte, norm_out;
+    float eps;
+    const float *scale_tok, *scale_byte;
+    const float *byte_rnorm;  // workspace: 1/rms of every byte-table row (norm_byte)
+    float *out;
+    int64_t *out_ids_padded, *out_ids_pulled, *counters;
+    uint32_t *status;
+    int tile_tokens, tiles_per_row;
+};
+
+__device__ __forceinline__ float rms_scale(float sumsq, int dim, float eps) {
+    // F.rms_norm: x * rsqrt(mean(x^2) + eps)   (train_gpt.py:172-173)
+    return 1.0f / sqrtf(sumsq / (float)dim + eps);
+}
+
+__device__ __forceinline__ int clamp_byte_id(int id, int64_t byte_rows, uint32_t *status) {
+    if ((uint64_t)(uint32_t)id >= (uint64_t)byte_rows) {
+        if (status) atomicOr(status, kStatusByteOor);
+        return 0;
+    }
+    return id;
+}
+
+// ------------------------------------------------------------------------------------------ phase 1
+// Leaves L.tok (token ids clamped to the ttb), L.ids (idsA, clamped to the byte table) and, when
+// `dual`, L.val (idsB, clamped) ready for phase 2.  Writes the optional parity outputs/counters.
+template <int DIR>
+__device__ __forceinline__ void phase1_from_ttb(const MixArgs &A, const TileLds &L, int64_t row, int64_t t0, int ntok) {
+    const int bpt = A.bpt, sv = bpt | 1;
+    SrcTable src{A.tokens + row * A.T, A.ttb, A.ttb_rows, A.ttb_elem, bpt, A.pad, A.eot, A.status};
+    if (DIR != kPullNone && (threadIdx.x >> 6) == kWaves - 1) halo_walk<DIR == kPullNone ? kPullLeft : DIR>(src, t0, ntok, A.T, bpt, L);
+    fill_table_tile(src, t0, ntok, bpt, L);
+    if (DIR != kPullNone) tile_scan_and_compact<DIR == kPullNone ? kPullLeft : DIR>(src, t0, ntok, A.T, bpt, L);
+    const SlotLayout S(bpt);
+    int pads_before = 0, pads_after = 0;
+    if (S.kq < bpt) {
+        const int64_t obase = (row * A.T + t0) * bpt;
+        for (int t = S.tq; t < ntok; t += S.tstride) {
+            const int own = L.val[t * sv + S.kq];
+            int v = own;
+            if (DIR != kPullNone) {
+                int kind;
+                const int payload = pulled_slot<DIR == kPullNone ? kPullLeft : DIR>(L, t, S.kq, ntok, bpt, &kind);
+                v = kind == 1 ? A.pad : (kind == 2 ? own : payload);
+            }
+            if (A.out_ids_padded) A.out_ids_padded[obase + t * bpt + S.kq] = own;
+            if (A.out_ids_pulled) A.out_ids_pulled[obase + t * bpt + S.kq] = v;
+            pads_before += own == A.pad;
+            pads_after += v == A.pad;
+            L.ids[t * sv + S.kq] = clamp_byte_id(v, A.byte_rows, A.status);
+        }
+    }
+    if (A.counters) {  // runs/79_mot-in_toks-valemb.py:484-488
+        pads_before = (int)wave_sum((float)pads_before);  // <= 64*64 per wave: exact in fp32
+        pads_after = (int)wave_sum((float)pads_after);
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd((unsigned long long *)A.counters + 2, (unsigned long long)pads_before);
+            atomicAdd((unsigned long long *)A.counters + 3, (unsigned long long)pads_after);
+        }
+        if (threadIdx.x == 0) {
+            atomicAdd((unsigned long long *)A.counters + 0, (unsigned long long)ntok);
+            atomicAdd((unsigned long long *)A.counters + 1, (unsigned long long)ntok * bpt);
+        }
+    }
+    __syncthreads();  // every pulled_slot read of L.val/stream is done
+    if (A.add_padded && S.kq < bpt)
+        for (int t = S.tq; t < ntok; t += S.tstride)
+            L.val[t * sv + S.kq] = clamp_byte_id(L.val[t * sv + S.kq], A.byte_rows, A.status);
+    __syncthreads();
+}
+
+__device__ __forceinline__ void phase1_given(const MixArgs &A, const TileLds &L, int64_t row, int64_t t0, int ntok) {
+    const int bpt = A.bpt, sv = bpt | 1;
+    if ((int)threadIdx.x < ntok) L.tok[threadIdx.x] = A.tokens[row * A.T + t0 + threadIdx.x];
+    const SlotLayout S(bpt);
+    if (S.kq < bpt) {
+        const int64_t ibase = (row * A.T + t0) * bpt;
+        for (int t = S.tq; t < ntok; t += S.tstride) {
+            const int64_t a = A.ids_a[ibase + t * bpt + S.kq];
+            int ia = (int)a;
+            if ((uint64_t)a >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); ia = 0; }
+            L.ids[t * sv + S.kq] = ia;
+            if (A.ids_b) {
+                const int64_t b = A.ids_b[ibase + t * bpt + S.kq];
+                int ib = (int)b;
+                if ((uint64_t)b >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); ib = 0; }
+                L.val[t * sv + S.kq] = ib;
+            }
+        }
+    }
+    if (A.counters && threadIdx.x == 0) {
+        atomicAdd((unsigned long long *)A.counters + 0, (unsigned long long)ntok);
+        atomicAdd((unsigned long long *)A.counters + 1, (unsigned long long)ntok * bpt);
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------ fused kernel
+// MODE: MOT_MIX_NOOP / SUM / MEAN.   NCH: float4 chunks per lane (covers Dm <= 256*NCH).
+// U: tokens in flight per wave.
+template <int MODE, int NCH, int U>
+__global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
+    extern __shared__ int32_t lds[];
+    const bool has_ids = MODE != MOT_MIX_NOOP;
+    const TileLds L = tile_lds_carve(lds, A.tile_tokens, has_ids ? A.bpt : 1, true);
+    const int64_t row = blockIdx.x / A.tiles_per_row;
+    const int64_t t0 = (int64_t)(blockIdx.x % A.tiles_per_row) * A.tile_tokens;
+    const int ntok = (int)min((int64_t)A.tile_tokens, A.T - t0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool dual = has_ids && (A.id_source == MOT_IDS_FROM_TTB ? A.add_padded != 0 : A.ids_b != nullptr);
+
+    if (!has_ids) {
+        if ((int)threadIdx.x < ntok) L.tok[threadIdx.x] = A.tokens[row * A.T + t0 + threadIdx.x];
+        if (A.counters && threadIdx.x == 0) atomicAdd((unsigned long long *)A.counters, (unsigned long long)ntok);
+        __syncthreads();
+    } else if (A.id_source == MOT_IDS_FROM_TTB) {
+        if (A.pull_dir == kPullLeft) phase1_from_ttb<kPullLeft>(A, L, row, t0, ntok);
+        else if (A.pull_dir == kPullRight) phase1_from_ttb<kPullRight>(A, L, row, t0, ntok);
+        else phase1_from_ttb<kPullNone>(A, L, row, t0, ntok);
+    } else {
+        phase1_given(A, L, row, t0, ntok);
+    }
+
+    // ---- phase 2
+    const int sv = A.bpt | 1;
+    const int Dm = A.Dt, nchunk = Dm >> 2;
+    int slot[NCH], within[NCH];
+    bool act[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int c = lane + 64 * i;
+        act[i] = c < nchunk;
+        const int cc = act[i] ? c : 0;
+        if (MODE == MOT_MIX_SUM) {
+            slot[i] = (4 * cc) / A.Db;            // concat_k: column j belongs to slot j / Db
+            within[i] = 4 * cc - slot[i] * A.Db;
+        } else {
+            slot[i] = 0;
+            within[i] = 4 * cc;
+        }
+    }
+    const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
+    const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
+    const bool scale_t = A.scale_tok != nullptr, scale_b = A.scale_byte != nullptr;
+    float *orow = A.out + (row * A.T + t0) * (int64_t)Dm;
+
+    for (int tb = wave * U; tb < ntok; tb += kWaves * U) {
+        float4v a[U][NCH], b[U][NCH];
+        // ---- issue every load of the U tokens before touching any of them
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = min(tb + u, ntok - 1);  // the tail re-reads the last token; its store is skipped
+            int tok = L.tok[t];
+            if ((uint64_t)(uint32_t)tok >= (uint64_t)A.tok_rows) {
+                if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
+                tok = 0;
+            }
+            const float *trow = A.tok_table + (int64_t)tok * Dm;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                a[u][i] = act[i] ? *(const float4v *)(trow + 4 * (lane + 64 * i)) : (float4v)(0.f);
+                if (MODE == MOT_MIX_SUM) {
+                    const int id = L.ids[t * sv + slot[i]];
+                    float4v v = *(const float4v *)(A.byte_table + (int64_t)id * A.Db + within[i]);
+                    if (dual) {  // norm(emb(padded) + emb(pulled)) without the norm (train_gpt.py:378)
+                        const int id2 = L.val[t * sv + slot[i]];
+                        v += *(const float4v *)(A.byte_table + (int64_t)id2 * A.Db + within[i]);
+                    }
+                    if (A.norm_byte) v *= A.byte_rnorm[id];
+                    b[u][i] = v;
+                } else if (MODE == MOT_MIX_MEAN) {
+                    float4v acc = (float4v)(0.f);
+                    for (int k = 0; k < A.bpt; ++k) {  // chars.mean(dim=-2), inference.py:267
+                        const int id = L.ids[t * sv + k];
+                        float4v v = *(const float4v *)(A.byte_table + (int64_t)id * A.Db + within[i]);
+                        if (dual) {
+                            const int id2 = L.val[t * sv + k];
+                            v += *(const float4v *)(A.byte_table + (int64_t)id2 * A.Db + within[i]);
+                        }
+                        if (A.norm_byte) v *= A.byte_rnorm[id];
+                        acc += v;
+                    }
+                    b[u][i] = acc / (float)A.bpt;
+                }
+            }
+        }
+        // ---- mix, normalise, store
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tb + u;
+            if (A.norm_tok) {
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) ss += a[u][i].x * a[u][i].x + a[u][i].y * a[u][i].y + a[u][i].z * a[u][i].z + a[u][i].w * a[u][i].w;
+                const float r = rms_scale(wave_sum(ss), Dm, A.eps);
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) a[u][i] *= r;
+            }
+            if (scale_t) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) a[u][i] *= s_tok;
+            }
+            float4v x[NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                if (MODE == MOT_MIX_NOOP) x[i] = a[u][i];
+                else x[i] = a[u][i] + (scale_b ? b[u][i] * s_byte : b[u][i]);
+            }
+            if (A.norm_out) {
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) ss += act[i] ? x[i].x * x[i].x + x[i].y * x[i].y + x[i].z * x[i].z + x[i].w * x[i].w : 0.f;
+                const float r = rms_scale(wave_sum(ss), Dm, A.eps);
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) x[i] *= r;
+            }
+            if (t < ntok) {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i)
+                    if (act[i]) __builtin_nontemporal_store(x[i], (float4v *)(orow + (int64_t)t * Dm + 4 * (lane + 64 * i)));
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ prologue
+// byte_rnorm[r] = rsqrt(mean(byte_table[r]^2) + eps): rms-norm of a gathered byte row depends on
+// the row only, so the per-slot reduction of norm(embed_bytes(ids)) (train_gpt.py:357,368)
+// collapses to one multiply in the fused kernel.  One wave per table row.
+__global__ __launch_bounds__(kThreads) void rows_rnorm_kernel(const float *__restrict__ table, int64_t rows, int dim,
+                                                              float eps, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float ss = 0.f;
+    for (int j = lane; j < dim; j += 64) {
+        const float v = table[r * dim + j];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) out[r] = rms_scale(ss, dim, eps);
+}
+
+// ------------------------------------------------------------------------------------------ seam gather
+// out[n] = scale * rms_norm?(table[idsA[n]] (+ table[idsB[n]])): the tensors FlexibleEmbedding.forward
+// returns (train_gpt.py:342-379).  G lanes cooperate on a row (G = 8..64 by row length).
+template <int G, typename IdT>
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const IdT *__restrict__ ids_a, const IdT *__restrict__ ids_b,
+                                                               int64_t n, const float *__restrict__ table, int64_t rows,
+                                                               int dim, int rms, float eps, const float *scale,
+                                                               float *__restrict__ out, uint32_t *status) {
+    const int g = threadIdx.x % G;
+    const int64_t per_block = kThreads / G;
+    const float s = scale ? *scale : 1.0f;
+    const bool vec = (dim & 3) == 0;
+    for (int64_t r = (int64_t)blockIdx.x * per_block + threadIdx.x / G; r < n; r += (int64_t)gridDim.x * per_block) {
+        int64_t ia = (int64_t)ids_a[r], ib = ids_b ? (int64_t)ids_b[r] : 0;
+        if ((uint64_t)ia >= (uint64_t)rows || (uint64_t)ib >= (uint64_t)rows) {
+            if (status) atomicOr(status, kStatusByteOor);
+            if ((uint64_t)ia >= (uint64_t)rows) ia = 0;
+            if ((uint64_t)ib >= (uint64_t)rows) ib = 0;
+        }
+        const float *pa = table + ia * dim, *pb = table + ib * dim;
+        float *po = out + r * dim;
+        float mult = s;
+        if (rms) {
+            float ss = 0.f;
+            if (vec) {
+                for (int j = g; j < (dim >> 2); j += G) {
+                    float4v v = *(const float4v *)(pa + 4 * j);
+                    if (ids_b) v += *(const float4v *)(pb + 4 * j);
+                    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+            } else {
+                for (int j = g; j < dim; j += G) {
+                    float v = pa[j];
+                    if (ids_b) v += pb[j];
+                    ss += v * v;
+                }
+            }
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, G);
+            mult = rms_scale(ss, dim, eps);
+        }
+        if (vec) {
+            for (int j = g; j < (dim >> 2); j += G) {
+                float4v v = *(const float4v *)(pa + 4 * j);
+                if (ids_b) v += *(const float4v *)(pb + 4 * j);
+                if (rms) v *= mult;
+                if (scale) v *= s;
+                __builtin_nontemporal_store(v, (float4v *)(po + 4 * j));
+            }
+        } else {
+            for (int j = g; j < dim; j += G) {
+                float v = pa[j];
+                if (ids_b) v += pb[j];
+                if (rms) v *= mult;
+                if (scale) v *= s;
+                po[j] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+template <int G>
+static int launch_gather_g(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const float *table,
+                           int64_t rows, int dim, int rms, float eps, const float *scale, float *out, uint32_t *status,
+                           hipStream_t stream) {
+    const int64_t per_block = kThreads / G;
+    int64_t blocks = (n + per_block - 1) / per_block;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (ids_elem == 8)
+        hipLaunchKernelGGL((gather_rows_kernel<G, int64_t>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
+                           (const int64_t *)ids_a, (const int64_t *)ids_b, n, table, rows, dim, rms, eps, scale, out, status);
+    else
+        hipLaunchKernelGGL((gather_rows_kernel<G, int32_t>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
+                           (const int32_t *)ids_a, (const int32_t *)ids_b, n, table, rows, dim, rms, eps, scale, out, status);
+    return check_launch("gather_rows_kernel");
+}
+
+int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const float *table, int64_t rows,
+                       int dim, int rms_norm, float eps, const float *scale, float *out, uint32_t *status,
+                       hipStream_t stream) {
+    if (n == 0) return MOT_OK;
+    if (eps <= 0.f) eps = FLT_EPSILON;
+    const int lanes = (dim & 3) == 0 ? dim / 4 : dim;
+    if (lanes <= 8) return launch_gather_g<8>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    if (lanes <= 16) return launch_gather_g<16>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    if (lanes <= 32) return launch_gather_g<32>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    return launch_gather_g<64>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+}
+
+size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d) {
+    if (d.mode == MOT_MIX_CONCAT_LINEAR) return embed_mix_linear_workspace_bytes(d);
+    if (d.mode != MOT_MIX_NOOP && d.norm_byte) return (size_t)d.byte_rows * sizeof(float);
+    return 0;
+}
+
+template <int MODE, int NCH, int U>
+static int launch_mix(const MixArgs &A, int64_t blocks, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
+    return check_launch("embed_mix_kernel");
+}
+
+template <int MODE>
+static int dispatch_nch(const MixArgs &A, int nch, int64_t blocks, size_t lds, hipStream_t stream) {
+    switch (nch) {
+        case 1: return launch_mix<MODE, 1, 4>(A, blocks, lds, stream);
+        case 2: return launch_mix<MODE, 2, 4>(A, blocks, lds, stream);
+        case 3: return launch_mix<MODE, 3, 2>(A, blocks, lds, stream);
+        case 4: return launch_mix<MODE, 4, 2>(A, blocks, lds, stream);
+        case 5:
+        case 6: return launch_mix<MODE, 6, 1>(A, blocks, lds, stream);
+        case 7:
+        case 8: return launch_mix<MODE, 8, 1>(A, blocks, lds, stream);
+        default: return set_error(MOT_EUNSUPPORTED, "embed_mix: model_dim %d > 2048 is not built", A.Dt);
+    }
+}
+
+int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
+    MixArgs A;
+    A.tokens = d.tokens; A.T = d.tokens_per_row; A.bpt = d.mode == MOT_MIX_NOOP ? 0 : d.bpt;
+    A.id_source = d.id_source; A.pull_dir = d.pull_dir; A.ttb = d.ttb; A.ttb_rows = d.ttb_rows;
+    A.ttb_elem = d.ttb_elem_bytes; A.add_padded = d.add_padded; A.pad = d.pad_byte; A.eot = d.eot_byte;
+    A.ids_a = d.ids_a; A.ids_b = d.ids_b;
+    A.tok_table = (const float *)d.tok_table; A.tok_rows = d.tok_rows; A.Dt = d.tok_dim;
+    A.byte_table = (const float *)d.byte_table; A.byte_rows = d.byte_rows; A.Db = d.byte_dim;
+    A.norm_tok = d.norm_tok; A.norm_byte = d.norm_byte; A.norm_out = d.norm_out;
+    A.eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    A.scale_tok = d.scale_tok; A.scale_byte = d.scale_byte;
+    A.byte_rnorm = nullptr;
+    A.out = (float *)d.out;
+    A.out_ids_padded = d.out_ids_padded; A.out_ids_pulled = d.out_ids_pulled; A.counters = d.counters;
+    A.status = d.status;
+
+    const int bpt_lds = d.mode == MOT_MIX_NOOP ? 1 : d.bpt;
+    A.tile_tokens = pick_tile_tokens(d.n_rows, d.tokens_per_row, bpt_lds, true);
+    const int64_t tiles_per_row = (d.tokens_per_row + A.tile_tokens - 1) / A.tile_tokens;
+    A.tiles_per_row = (int)tiles_per_row;
+    const int64_t blocks = d.n_rows * tiles_per_row;
+    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix: too many tiles");
+    const size_t lds = tile_lds_bytes(A.tile_tokens, bpt_lds, true);
+
+    if (d.mode != MOT_MIX_NOOP && d.norm_byte) {
+        const size_t need = (size_t)d.byte_rows * sizeof(float);
+        if (!d.workspace || d.workspace_bytes < need)
+            return set_error(MOT_EWORKSPACE, "embed_mix: norm_byte needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
+        float *rn = (float *)d.workspace;
+        const int64_t rb = (d.byte_rows + kWaves - 1) / kWaves;
+        hipLaunchKernelGGL(rows_rnorm_kernel, dim3((unsigned)rb), dim3(kThreads), 0, stream, A.byte_table, d.byte_rows,
+                           d.byte_dim, A.eps, rn);
+        int rc = check_launch("rows_rnorm_kernel");
+        if (rc) return rc;
+        A.byte_rnorm = rn;
+    }
+    const int nch = (d.tok_dim / 4 + 63) / 64;
+    switch (d.mode) {
+        case MOT_MIX_NOOP: return dispatch_nch<MOT_MIX_NOOP>(A, nch, blocks, lds, stream);
+        case MOT_MIX_SUM: return dispatch_nch<MOT_MIX_SUM>(A, nch, blocks, lds, stream);
+        case MOT_MIX_MEAN: return dispatch_nch<MOT_MIX_MEAN>(A, nch, blocks, lds, stream);
+        default: return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d.mode);
+    }
+}
+
+}  // namespace mot

@@ -1,0 +1,32 @@
+// mot_internal.hpp -- host-side declarations shared by the translation units of libmot_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mot.h"
+
+namespace mot {
+
+// Records a thread-local message for mot_last_error() and returns `code`.
+int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+// hipGetLastError() after a launch -> MOT_OK / MOT_EHIP (with the kernel name in the message).
+int check_launch(const char *what);
+
+int pick_tile_tokens(int64_t n_rows, int64_t tokens_per_row, int bpt, bool with_ids);
+
+int launch_tokens_to_bytes(const int32_t *tokens, int64_t n_tokens, const void *ttb, int elem, int64_t ttb_rows,
+                           int bpt, int64_t *out, uint32_t *status, hipStream_t stream);
+int launch_pull_bytes(const int64_t *in, int64_t *out, int64_t B, int64_t tokens_per_row, int bpt, int64_t pad,
+                      int64_t eot, int dir, hipStream_t stream);
+int launch_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *ttb_left, const void *ttb_right,
+                        int elem, int64_t ttb_rows, int bpt, int32_t pad, int32_t eot, int64_t *out, uint32_t *status,
+                        hipStream_t stream);
+int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const float *table, int64_t rows,
+                       int dim, int rms_norm, float eps, const float *scale, float *out, uint32_t *status,
+                       hipStream_t stream);
+size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d);
+int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream);         // SUM / MEAN / NOOP
+int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream);  // CONCAT_LINEAR
+size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d);
+
+}  // namespace mot

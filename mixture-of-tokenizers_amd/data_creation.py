@@ -1,0 +1,107 @@
+"""Drop-in for the byte-index producer of the reference loader: same function names, argument
+order and return shapes/dtypes as scaled-pre-train/data_creation.py:43-330, so that
+``from data_creation import make_embedding, tokens_to_bytes, pull_from_left, pull_from_right``
+(train_gpt.py:31, data_loader.py:17) can point here unchanged.  All work runs in HIP kernels
+on the tensors' device; there is no host synchronisation (the reference's per-row
+``nonzero``/``searchsorted`` loop syncs at least twice per batch row).
+"""
+from __future__ import annotations
+
+import json
+
+import torch
+from torch import nn
+
+from . import functional as F_mot
+
+
+def load_ttb(filename: str) -> dict[int, list[int]]:
+    """data_creation.py:43-48: ``embeddings/<filename>`` JSON {token id: [byte ids]}."""
+    with open(f"embeddings/{filename}", "r") as f:
+        ttb = json.loads(f.read())
+    return {int(k): [int(x) for x in v] for k, v in ttb.items()}
+
+
+class TokenToBytesTable(nn.Embedding):
+    """What make_embedding returns: an ``nn.Embedding`` (so ``.to(device)``, ``isinstance`` checks
+    and ``.weight`` keep working, train_gpt.py:666-672) whose fp32 weight holds integers.  The
+    kernels read an int16/int32 copy of it, rebuilt when the weight moves or changes."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__(num_embeddings, embedding_dim)  # same RNG draw as the reference (quirk: rows
+        self.weight.requires_grad = False                # absent from the JSON keep this random init)
+        self._int_cache: tuple | None = None
+
+    def int_table(self) -> torch.Tensor:
+        w = self.weight
+        key = (w.data_ptr(), w._version, w.device, w.dtype)
+        if self._int_cache is None or self._int_cache[0] != key:
+            self._int_cache = (key, int_table_of(w))
+        return self._int_cache[1]
+
+
+def int_table_of(weight: torch.Tensor) -> torch.Tensor:
+    """fp32 table -> integer table with the reference's cast (``.to(torch.int64)`` = truncation,
+    data_creation.py:63); int16 when every id fits (458 byte ids do), else int32."""
+    t = weight.detach().to(torch.int64)
+    if t.numel() and int(t.abs().max()) >= 2 ** 15:
+        return t.to(torch.int32).contiguous()
+    return t.to(torch.int16).contiguous()
+
+
+def make_embedding(filename: str, vocab_size: int) -> nn.Embedding:
+    """data_creation.py:51-58 (``dim`` is parsed from ``ttb_<dim>_...json``)."""
+    dim = int(filename.split("_")[1])
+    emb = TokenToBytesTable(vocab_size, dim)
+    ttb = load_ttb(filename)
+    idx = torch.tensor(sorted(ttb), dtype=torch.long)
+    rows = torch.tensor([ttb[int(i)] for i in idx], dtype=emb.weight.dtype)
+    with torch.no_grad():
+        emb.weight.data[idx] = rows
+    emb.weight.requires_grad = False
+    return emb
+
+
+_plain_cache: dict[int, tuple] = {}
+
+
+def _table_of(emb) -> torch.Tensor:
+    if isinstance(emb, TokenToBytesTable):
+        return emb.int_table()
+    if isinstance(emb, nn.Embedding):  # e.g. built by the reference's own make_embedding
+        w = emb.weight
+        key = (w.data_ptr(), w._version, w.device, w.dtype)
+        hit = _plain_cache.get(id(emb))
+        if hit is None or hit[0] != key:
+            hit = (key, int_table_of(w))
+            _plain_cache[id(emb)] = hit
+        return hit[1]
+    if isinstance(emb, torch.Tensor):
+        return emb if emb.dtype in (torch.int16, torch.int32) else int_table_of(emb)
+    raise TypeError(f"unsupported token->byte table: {type(emb)}")
+
+
+def tokens_to_bytes(tokens: torch.Tensor, emb) -> torch.Tensor:
+    """data_creation.py:61-67: (B, T) -> (B, T*bpt) int64; 1-D (T,) -> (1, T*bpt)."""
+    out = F_mot.tokens_to_bytes(tokens, _table_of(emb))
+    if tokens.ndim == 2:
+        return out.view(out.shape[0], -1)
+    return out.view(-1).unsqueeze(0)
+
+
+def pull_from_right(byte_tensor: torch.Tensor, bytes_per_token: int, pad_byte: int, eot_byte: int) -> torch.Tensor:
+    """data_creation.py:71-176."""
+    return F_mot.pull_bytes(byte_tensor, bytes_per_token, pad_byte, eot_byte, "right")
+
+
+def pull_from_left(byte_tensor: torch.Tensor, bytes_per_token: int, pad_byte: int, eot_byte: int) -> torch.Tensor:
+    """data_creation.py:179-305."""
+    return F_mot.pull_bytes(byte_tensor, bytes_per_token, pad_byte, eot_byte, "left")
+
+
+def create_batch(tokens: torch.Tensor, bytes_per_token: int, pad_byte: int, eot_byte: int,
+                 tokens_to_bytes_right_pad, tokens_to_bytes_left_pad) -> torch.Tensor:
+    """data_creation.py:308-330: (B, T, 1 + 4*bpt), dtype int64 (torch.cat promotes the int32 tokens)."""
+    tl, tr = _table_of(tokens_to_bytes_left_pad), _table_of(tokens_to_bytes_right_pad)
+    assert tl.shape[1] == bytes_per_token
+    return F_mot.create_batch(tokens, tl, tr, pad_byte, eot_byte)

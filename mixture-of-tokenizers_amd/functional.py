@@ -1,0 +1,231 @@
+"""Tensor-level wrappers of the C ABI: shape/dtype/device checks, output allocation on the
+caller's device and stream (torch caching allocator), then one call into libmot_hip.so.
+
+Nothing here computes: every result comes from a HIP kernel.  Functions are wrapped in
+``torch.compiler.disable`` so that a caller under ``torch.compile`` (train_gpt.py:1195) sees
+them as opaque calls.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _capi as capi
+
+_MODES = {"noop": capi.MIX_NOOP, "sum": capi.MIX_SUM, "mean": capi.MIX_MEAN, "concat_linear": capi.MIX_CONCAT_LINEAR}
+_PULLS = {None: capi.PULL_NONE, "none": capi.PULL_NONE, "left": capi.PULL_LEFT, "right": capi.PULL_RIGHT}
+
+
+def _contig(t: torch.Tensor, dtype: torch.dtype, what: str) -> torch.Tensor:
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _int_table(table: torch.Tensor, what: str) -> torch.Tensor:
+    if table.dtype not in (torch.int16, torch.int32):
+        raise TypeError(f"{what}: token->byte table must be int16 or int32, got {table.dtype}")
+    if table.ndim != 2:
+        raise ValueError(f"{what}: token->byte table must be (vocab, bytes_per_token)")
+    return table if table.is_contiguous() else table.contiguous()
+
+
+@torch.compiler.disable
+def tokens_to_bytes(tokens: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """int64 byte ids of `tokens` (any shape) from an integer table (vocab, bpt) -> tokens.shape + (bpt,)."""
+    table = _int_table(table, "tokens_to_bytes")
+    dev = capi.require_device(tokens, table)
+    tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
+    tok = tok if tok.is_contiguous() else tok.contiguous()
+    bpt = table.shape[1]
+    out = torch.empty(tok.shape + (bpt,), dtype=torch.int64, device=dev)
+    capi.check(capi.lib.mot_tokens_to_bytes(capi.ptr(tok), tok.numel(), capi.ptr(table), table.element_size(),
+                                            table.shape[0], bpt, capi.ptr(out), capi.ptr(capi.status_word(dev)),
+                                            capi.stream_of(dev)))
+    capi.after_call(dev)
+    return out
+
+
+@torch.compiler.disable
+def pull_bytes(byte_tensor: torch.Tensor, bytes_per_token: int, pad_byte: int, eot_byte: int, direction: str) -> torch.Tensor:
+    """pull_from_left / pull_from_right on a (B, T) int64 tensor (data_creation.py:71-305)."""
+    if byte_tensor.ndim != 2:
+        raise ValueError("byte_tensor must be (B, T)")
+    B, T = byte_tensor.shape
+    if T == 0:
+        return byte_tensor  # data_creation.py:82-83, 190
+    dev = capi.require_device(byte_tensor)
+    x = _contig(byte_tensor, torch.int64, "byte_tensor")
+    out = torch.empty_like(x)
+    capi.check(capi.lib.mot_pull_bytes(capi.ptr(x), capi.ptr(out), B, T, int(bytes_per_token), int(pad_byte),
+                                       int(eot_byte), _PULLS[direction], capi.stream_of(dev)))
+    return out
+
+
+@torch.compiler.disable
+def create_batch(tokens: torch.Tensor, table_left: torch.Tensor, table_right: torch.Tensor, pad_byte: int, eot_byte: int) -> torch.Tensor:
+    """(B, T, 1+4*bpt) int64 packed batch (data_creation.py:308-330) in one launch."""
+    tl, tr = _int_table(table_left, "create_batch"), _int_table(table_right, "create_batch")
+    if tl.shape != tr.shape or tl.dtype != tr.dtype:
+        raise ValueError("left/right tables must have the same shape and dtype")
+    dev = capi.require_device(tokens, tl, tr)
+    tok = _contig(tokens.to(torch.int32), torch.int32, "tokens")
+    B, T = tok.shape
+    bpt = tl.shape[1]
+    out = torch.empty((B, T, 1 + 4 * bpt), dtype=torch.int64, device=dev)
+    capi.check(capi.lib.mot_create_batch(capi.ptr(tok), B, T, capi.ptr(tl), capi.ptr(tr), tl.element_size(), tl.shape[0],
+                                         bpt, int(pad_byte), int(eot_byte), capi.ptr(out),
+                                         capi.ptr(capi.status_word(dev)), capi.stream_of(dev)))
+    capi.after_call(dev)
+    return out
+
+
+@torch.compiler.disable
+def gather_rows(table: torch.Tensor, ids: torch.Tensor, ids_b: torch.Tensor | None = None, *, rms_norm: bool = False,
+                eps: float | None = None, scale: torch.Tensor | None = None) -> torch.Tensor:
+    """scale * rms_norm?(table[ids] (+ table[ids_b])) -> ids.shape + (dim,)  (train_gpt.py:342-379)."""
+    dev = capi.require_device(table, ids, ids_b, scale)
+    tab = _contig(table, torch.float32, "table")
+    if ids.dtype not in (torch.int32, torch.int64):
+        raise TypeError(f"ids must be int32/int64, got {ids.dtype}")
+    ia = ids if ids.is_contiguous() else ids.contiguous()
+    ib = None
+    if ids_b is not None:
+        if ids_b.shape != ids.shape or ids_b.dtype != ids.dtype:
+            raise ValueError("ids_b must match ids in shape and dtype")
+        ib = ids_b if ids_b.is_contiguous() else ids_b.contiguous()
+    out = torch.empty(ids.shape + (tab.shape[1],), dtype=torch.float32, device=dev)
+    capi.check(capi.lib.mot_gather_rows(capi.ptr(ia), capi.ptr(ib), ia.element_size(), ia.numel(), capi.ptr(tab),
+                                        tab.shape[0], tab.shape[1], int(rms_norm), float(eps or 0.0), capi.ptr(scale),
+                                        capi.ptr(out), capi.ptr(capi.status_word(dev)), capi.stream_of(dev)))
+    capi.after_call(dev)
+    return out
+
+
+@dataclass
+class MixResult:
+    x: torch.Tensor
+    ids_padded: torch.Tensor | None = None
+    ids_pulled: torch.Tensor | None = None
+
+
+_workspaces: dict[tuple[int, int], torch.Tensor] = {}
+
+
+def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor | None:
+    """Per-(device, stream) scratch reused across calls (kernels on one stream are ordered)."""
+    if nbytes == 0:
+        return None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), capi.stream_of(dev))
+    w = _workspaces.get(key)
+    if w is None or w.numel() < nbytes:
+        w = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _workspaces[key] = w
+    return w
+
+
+@torch.compiler.disable
+def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor | None = None, *,
+              mode: str, bpt: int = 0,
+              ttb: torch.Tensor | None = None, pull: str | None = None, add_padded: bool = False,
+              pad_byte: int = 456, eot_byte: int = 457,
+              ids_a: torch.Tensor | None = None, ids_b: torch.Tensor | None = None,
+              weight: torch.Tensor | None = None, bias: torch.Tensor | None = None, bytes_first: bool = False,
+              norm_tok: bool = False, norm_byte: bool = False, norm_out: bool = False, eps: float | None = None,
+              scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
+              out: torch.Tensor | None = None, return_ids: bool = False,
+              counters: torch.Tensor | None = None) -> torch.Tensor | MixResult:
+    """One fused launch of mot_embed_mix_fwd; see include/mot.h for the per-token formula.
+
+    tokens (B, T) integer.  Byte ids either come from `ttb` (+ `pull` = "left" | "right" | None,
+    + `add_padded`) inside the kernel, or are given as `ids_a` / `ids_b` (B, T*bpt) int64.
+    `scale_*` are 0-dim/1-element DEVICE tensors (learned scalars are read on the device).
+    """
+    m = _MODES[mode]
+    if tokens.ndim == 1:
+        tokens = tokens[None]
+    if tokens.ndim != 2:
+        raise ValueError("tokens must be (B, T) or (T,)")
+    dev = capi.require_device(tokens, tok_table, byte_table, ttb, ids_a, ids_b, weight, bias, scale_tok, scale_byte)
+    tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
+    tok = tok if tok.is_contiguous() else tok.contiguous()
+    B, T = tok.shape
+    tt = _contig(tok_table, torch.float32, "tok_table")
+    d = capi.MotEmbedMixDesc()
+    d.struct_size = C.sizeof(capi.MotEmbedMixDesc)
+    d.dtype = capi.F32
+    d.n_rows, d.tokens_per_row, d.bpt, d.mode = B, T, int(bpt), m
+    d.tokens = capi.ptr(tok)
+    d.tok_table, d.tok_rows, d.tok_dim = capi.ptr(tt), tt.shape[0], tt.shape[1]
+    keep = [tok, tt]
+    ids_padded = ids_pulled = None
+    if m != capi.MIX_NOOP:
+        if byte_table is None:
+            raise ValueError("byte_table is required unless mode == 'noop'")
+        bt = _contig(byte_table, torch.float32, "byte_table")
+        keep.append(bt)
+        d.byte_table, d.byte_rows, d.byte_dim = capi.ptr(bt), bt.shape[0], bt.shape[1]
+        if ttb is not None:
+            tab = _int_table(ttb, "embed_mix")
+            if tab.shape[1] != bpt:
+                raise ValueError(f"ttb has {tab.shape[1]} slots per token, bpt={bpt}")
+            keep.append(tab)
+            d.id_source, d.pull_dir = capi.IDS_FROM_TTB, _PULLS[pull]
+            d.ttb, d.ttb_rows, d.ttb_elem_bytes = capi.ptr(tab), tab.shape[0], tab.element_size()
+            d.add_padded = int(add_padded)
+            if return_ids:
+                ids_padded = torch.empty((B, T * bpt), dtype=torch.int64, device=dev)
+                ids_pulled = torch.empty((B, T * bpt), dtype=torch.int64, device=dev)
+                d.out_ids_padded, d.out_ids_pulled = capi.ptr(ids_padded), capi.ptr(ids_pulled)
+        else:
+            if ids_a is None:
+                raise ValueError("either ttb or ids_a must be given")
+            ia = _contig(ids_a, torch.int64, "ids_a")
+            assert ia.numel() == B * T * bpt, "byte ids must hold bytes_per_token ids per token"
+            keep.append(ia)
+            d.id_source, d.ids_a = capi.IDS_GIVEN, capi.ptr(ia)
+            if ids_b is not None:
+                ib = _contig(ids_b, torch.int64, "ids_b")
+                assert ib.numel() == ia.numel()
+                keep.append(ib)
+                d.ids_b = capi.ptr(ib)
+    d.pad_byte, d.eot_byte = int(pad_byte), int(eot_byte)
+    if m == capi.MIX_CONCAT_LINEAR:
+        if weight is None:
+            raise ValueError("weight is required for mode == 'concat_linear'")
+        w = _contig(weight, torch.float32, "weight")
+        keep.append(w)
+        d.weight, d.model_dim = capi.ptr(w), w.shape[0]
+        if w.shape[1] != tt.shape[1] + bpt * d.byte_dim:
+            raise ValueError(f"weight has {w.shape[1]} input features, expected {tt.shape[1]} + {bpt}*{d.byte_dim}")
+        if bias is not None:
+            bs = _contig(bias, torch.float32, "bias")
+            keep.append(bs)
+            d.bias = capi.ptr(bs)
+        d.bytes_first = int(bytes_first)
+    else:
+        d.model_dim = tt.shape[1]
+    d.norm_tok, d.norm_byte, d.norm_out = int(norm_tok), int(norm_byte), int(norm_out)
+    d.eps = float(eps or 0.0)
+    d.scale_tok, d.scale_byte = capi.ptr(scale_tok), capi.ptr(scale_byte)
+    if out is None:
+        out = torch.empty((B, T, d.model_dim), dtype=torch.float32, device=dev)
+    else:
+        if out.shape != (B, T, d.model_dim) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise ValueError("out must be a contiguous float32 (B, T, model_dim) tensor on the inputs' device")
+    d.out = capi.ptr(out)
+    if counters is not None:
+        if counters.dtype != torch.int64 or counters.numel() < 4 or counters.device != dev:
+            raise ValueError("counters must be an int64[4] tensor on the inputs' device")
+        d.counters = capi.ptr(counters)
+    d.status = capi.ptr(capi.status_word(dev))
+    ws = _workspace(dev, capi.lib.mot_embed_mix_workspace_bytes(C.byref(d)))
+    if ws is not None:
+        d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
+    capi.check(capi.lib.mot_embed_mix_fwd(C.byref(d), capi.stream_of(dev)))
+    capi.after_call(dev)
+    if return_ids:
+        return MixResult(out, ids_padded, ids_pulled)
+    return out
