@@ -85,13 +85,26 @@ def algorithmic_bytes_per_token(wl, ids_mode):
     return r + e * D
 
 
+def usable_cores() -> int:
+    """Threads the CPU baseline may really use: affinity, capped by the cgroup CPU quota and by the
+    GPU box's per-GPU CPU share (16), so OpenMP does not oversubscribe."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("MOT_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(wl, inp, seconds):
     """The oracle (oracle/mot_oracle.c, OpenMP) on this host: tokens_to_bytes + pull_from_left +
     gather/sum/rms-norm in fp32 on rows of the same workload, repeated for ~`seconds`."""
     from oracle import oracle as orc
     import golden_inputs as gi
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     orc.set_threads(cores)
     Et, Eb = inp["tok_table"].cpu().numpy(), inp["byte_table"].cpu().numpy()
     rows = min(B, 32)
