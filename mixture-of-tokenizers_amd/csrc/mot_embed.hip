@@ -11,130 +11,9 @@
 //            rms-norm reductions are wave shuffles, the mixed row is written once with
 //            non-temporal 16 B stores.  Algorithmic traffic: 4 + 2*bpt + 4*Dt B read and
 //            4*Dm B written per token; HBM-bound.
-#include <float.h>
-
-#include "mot_internal.hpp"
-#include "mot_tile.hpp"
+#include "mot_mix.hpp"
 
 namespace mot {
-
-typedef float float4v __attribute__((ext_vector_type(4)));
-
-struct MixArgs {
-    // ids
-    const int32_t *tokens;
-    int64_t T;  // tokens per row
-    int bpt;
-    int id_source, pull_dir;
-    const void *ttb;
-    int64_t ttb_rows;
-    int ttb_elem;
-    int add_padded;
-    int32_t pad, eot;
-    const int64_t *ids_a, *ids_b;
-    // tables
-    const float *tok_table;
-    int64_t tok_rows;
-    int Dt;
-    const float *byte_table;
-    int64_t byte_rows;
-    int Db;
-    int norm_tok, norm_byte, norm_out;
-    float eps;
-    const float *scale_tok, *scale_byte;
-    const float *byte_rnorm;  // workspace: 1/rms of every byte-table row (norm_byte)
-    float *out;
-    int64_t *out_ids_padded, *out_ids_pulled, *counters;
-    uint32_t *status;
-    int tile_tokens, tiles_per_row;
-};
-
-__device__ __forceinline__ float rms_scale(float sumsq, int dim, float eps) {
-    // F.rms_norm: x * rsqrt(mean(x^2) + eps)   (train_gpt.py:172-173)
-    return 1.0f / sqrtf(sumsq / (float)dim + eps);
-}
-
-__device__ __forceinline__ int clamp_byte_id(int id, int64_t byte_rows, uint32_t *status) {
-    if ((uint64_t)(uint32_t)id >= (uint64_t)byte_rows) {
-        if (status) atomicOr(status, kStatusByteOor);
-        return 0;
-    }
-    return id;
-}
-
-// ------------------------------------------------------------------------------------------ phase 1
-// Leaves L.tok (token ids clamped to the ttb), L.ids (idsA, clamped to the byte table) and, when
-// `dual`, L.val (idsB, clamped) ready for phase 2.  Writes the optional parity outputs/counters.
-template <int DIR>
-__device__ __forceinline__ void phase1_from_ttb(const MixArgs &A, const TileLds &L, int64_t row, int64_t t0, int ntok) {
-    const int bpt = A.bpt, sv = bpt | 1;
-    SrcTable src{A.tokens + row * A.T, A.ttb, A.ttb_rows, A.ttb_elem, bpt, A.pad, A.eot, A.status};
-    if (DIR != kPullNone && (threadIdx.x >> 6) == kWaves - 1) halo_walk<DIR == kPullNone ? kPullLeft : DIR>(src, t0, ntok, A.T, bpt, L);
-    fill_table_tile(src, t0, ntok, bpt, L);
-    if (DIR != kPullNone) tile_scan_and_compact<DIR == kPullNone ? kPullLeft : DIR>(src, t0, ntok, A.T, bpt, L);
-    const SlotLayout S(bpt);
-    int pads_before = 0, pads_after = 0;
-    if (S.kq < bpt) {
-        const int64_t obase = (row * A.T + t0) * bpt;
-        for (int t = S.tq; t < ntok; t += S.tstride) {
-            const int own = L.val[t * sv + S.kq];
-            int v = own;
-            if (DIR != kPullNone) {
-                int kind;
-                const int payload = pulled_slot<DIR == kPullNone ? kPullLeft : DIR>(L, t, S.kq, ntok, bpt, &kind);
-                v = kind == 1 ? A.pad : (kind == 2 ? own : payload);
-            }
-            if (A.out_ids_padded) A.out_ids_padded[obase + t * bpt + S.kq] = own;
-            if (A.out_ids_pulled) A.out_ids_pulled[obase + t * bpt + S.kq] = v;
-            pads_before += own == A.pad;
-            pads_after += v == A.pad;
-            L.ids[t * sv + S.kq] = clamp_byte_id(v, A.byte_rows, A.status);
-        }
-    }
-    if (A.counters) {  // runs/79_mot-in_toks-valemb.py:484-488
-        pads_before = (int)wave_sum((float)pads_before);  // <= 64*64 per wave: exact in fp32
-        pads_after = (int)wave_sum((float)pads_after);
-        if ((threadIdx.x & 63) == 0) {
-            atomicAdd((unsigned long long *)A.counters + 2, (unsigned long long)pads_before);
-            atomicAdd((unsigned long long *)A.counters + 3, (unsigned long long)pads_after);
-        }
-        if (threadIdx.x == 0) {
-            atomicAdd((unsigned long long *)A.counters + 0, (unsigned long long)ntok);
-            atomicAdd((unsigned long long *)A.counters + 1, (unsigned long long)ntok * bpt);
-        }
-    }
-    __syncthreads();  // every pulled_slot read of L.val/stream is done
-    if (A.add_padded && S.kq < bpt)
-        for (int t = S.tq; t < ntok; t += S.tstride)
-            L.val[t * sv + S.kq] = clamp_byte_id(L.val[t * sv + S.kq], A.byte_rows, A.status);
-    __syncthreads();
-}
-
-__device__ __forceinline__ void phase1_given(const MixArgs &A, const TileLds &L, int64_t row, int64_t t0, int ntok) {
-    const int bpt = A.bpt, sv = bpt | 1;
-    if ((int)threadIdx.x < ntok) L.tok[threadIdx.x] = A.tokens[row * A.T + t0 + threadIdx.x];
-    const SlotLayout S(bpt);
-    if (S.kq < bpt) {
-        const int64_t ibase = (row * A.T + t0) * bpt;
-        for (int t = S.tq; t < ntok; t += S.tstride) {
-            const int64_t a = A.ids_a[ibase + t * bpt + S.kq];
-            int ia = (int)a;
-            if ((uint64_t)a >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); ia = 0; }
-            L.ids[t * sv + S.kq] = ia;
-            if (A.ids_b) {
-                const int64_t b = A.ids_b[ibase + t * bpt + S.kq];
-                int ib = (int)b;
-                if ((uint64_t)b >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); ib = 0; }
-                L.val[t * sv + S.kq] = ib;
-            }
-        }
-    }
-    if (A.counters && threadIdx.x == 0) {
-        atomicAdd((unsigned long long *)A.counters + 0, (unsigned long long)ntok);
-        atomicAdd((unsigned long long *)A.counters + 1, (unsigned long long)ntok * bpt);
-    }
-    __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------ fused kernel
 // MODE: MOT_MIX_NOOP / SUM / MEAN.   NCH: float4 chunks per lane (covers Dm <= 256*NCH).
@@ -372,6 +251,12 @@ int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64
     return launch_gather_g<64>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
 }
 
+int launch_rows_rnorm(const float *table, int64_t rows, int dim, float eps, float *out, hipStream_t stream) {
+    const int64_t rb = (rows + kWaves - 1) / kWaves;
+    hipLaunchKernelGGL(rows_rnorm_kernel, dim3((unsigned)rb), dim3(kThreads), 0, stream, table, rows, dim, eps, out);
+    return check_launch("rows_rnorm_kernel");
+}
+
 size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d) {
     if (d.mode == MOT_MIX_CONCAT_LINEAR) return embed_mix_linear_workspace_bytes(d);
     if (d.mode != MOT_MIX_NOOP && d.norm_byte) return (size_t)d.byte_rows * sizeof(float);
@@ -401,19 +286,7 @@ static int dispatch_nch(const MixArgs &A, int nch, int64_t blocks, size_t lds, h
 
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
     MixArgs A;
-    A.tokens = d.tokens; A.T = d.tokens_per_row; A.bpt = d.mode == MOT_MIX_NOOP ? 0 : d.bpt;
-    A.id_source = d.id_source; A.pull_dir = d.pull_dir; A.ttb = d.ttb; A.ttb_rows = d.ttb_rows;
-    A.ttb_elem = d.ttb_elem_bytes; A.add_padded = d.add_padded; A.pad = d.pad_byte; A.eot = d.eot_byte;
-    A.ids_a = d.ids_a; A.ids_b = d.ids_b;
-    A.tok_table = (const float *)d.tok_table; A.tok_rows = d.tok_rows; A.Dt = d.tok_dim;
-    A.byte_table = (const float *)d.byte_table; A.byte_rows = d.byte_rows; A.Db = d.byte_dim;
-    A.norm_tok = d.norm_tok; A.norm_byte = d.norm_byte; A.norm_out = d.norm_out;
-    A.eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
-    A.scale_tok = d.scale_tok; A.scale_byte = d.scale_byte;
-    A.byte_rnorm = nullptr;
-    A.out = (float *)d.out;
-    A.out_ids_padded = d.out_ids_padded; A.out_ids_pulled = d.out_ids_pulled; A.counters = d.counters;
-    A.status = d.status;
+    fill_mix_args(A, d);
 
     const int bpt_lds = d.mode == MOT_MIX_NOOP ? 1 : d.bpt;
     A.tile_tokens = pick_tile_tokens(d.n_rows, d.tokens_per_row, bpt_lds, true);
@@ -428,10 +301,7 @@ int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
         if (!d.workspace || d.workspace_bytes < need)
             return set_error(MOT_EWORKSPACE, "embed_mix: norm_byte needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
         float *rn = (float *)d.workspace;
-        const int64_t rb = (d.byte_rows + kWaves - 1) / kWaves;
-        hipLaunchKernelGGL(rows_rnorm_kernel, dim3((unsigned)rb), dim3(kThreads), 0, stream, A.byte_table, d.byte_rows,
-                           d.byte_dim, A.eps, rn);
-        int rc = check_launch("rows_rnorm_kernel");
+        int rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rn, stream);
         if (rc) return rc;
         A.byte_rnorm = rn;
     }

@@ -1,12 +1,356 @@
-// mot_linear.hip -- CONCAT_LINEAR mode of the fused front-end (placeholder until the MFMA kernel lands).
-#include "mot_internal.hpp"
+// mot_linear.hip -- CONCAT_LINEAR mode of the fused front-end (gfx950):
+//     x = rms_norm?( W . cat(a, b_0 .. b_{bpt-1}) + bias )
+// i.e. ByteMixinConcat after FlexibleEmbedding (scaled-pre-train/train_gpt.py:327-379, 430-443:
+// tokens first, no bias, norms everywhere) and DigitMixinConcat after wte/dte
+// (mathblations/model.py:256-268, 323-327: digits first, bias, no norms).
+//
+// This mode is a dense contraction over K = Dt + bpt*Db per token (~285 FLOP/B at
+// K = Dm = 768), so it is MFMA-bound, not HBM-bound, and uses the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain: no precision is traded away).  What makes it a
+// *fused* kernel is the A operand: the (tokens x K) concat matrix is never materialised -- each
+// K-step's A tile is gathered straight from the embedding tables (rows chosen by the token ids and
+// by the byte ids that phase 1 left in LDS), scaled by the per-segment rms factor and written to
+// LDS k-major, where it is consumed as MFMA fragments.
+//
+// Geometry: one 256-thread workgroup (4 waves, one per SIMD, so each wave may use the whole
+// 512-entry register file) per tile of 64 tokens x all Dm output columns -- the post-norm needs
+// complete rows.  Wave w owns columns [w*NT*32, (w+1)*NT*32): 2 x NT accumulator tiles of 32x32.
+// K is walked in steps of 16 with double-buffered LDS: the next step's W chunk (from the k-major
+// transposed copy the prologue kernel writes to the workspace) and A chunk are loaded to registers
+// before the current step's MFMAs and written to the other buffer after them; one barrier per step.
+#include "mot_mix.hpp"
 
 namespace mot {
 
-size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &) { return 0; }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-int launch_embed_mix_linear(const MotEmbedMixDesc &, hipStream_t) {
-    return set_error(MOT_EUNSUPPORTED, "embed_mix: CONCAT_LINEAR is not built yet");
+constexpr int kTM = 64;  // tokens per workgroup tile
+constexpr int kBKmax = 16;  // K-step is 16 (8 for the widest accumulator tile, to stay inside 512 registers)
+
+struct LinArgs {
+    MixArgs M;
+    const float *Wt;    // [Kpad, DmPad] k-major copy of the weight, zero padded
+    const float *bias;  // [Dm] or null
+    int K, Kpad, Dm, DmPad, bytes_first, dual;
+};
+
+struct LinLds {
+    float *W0, *A0, *scale, *rowss;  // W0/A0: two consecutive buffers each
+    int32_t *tokc;
+    TileLds tile;
+};
+
+__host__ __device__ inline size_t lin_lds_floats_before_tile(int DmPad, int bpt, int bk) {
+    return 2 * (size_t)bk * DmPad + 2 * (size_t)bk * kTM + (size_t)kTM * (1 + bpt) + 4 * kTM + kTM;
+}
+__host__ __device__ inline size_t lin_lds_bytes(int DmPad, int bpt, int bk) {
+    size_t f = lin_lds_floats_before_tile(DmPad, bpt, bk);
+    f = (f + 3) & ~(size_t)3;
+    return f * 4 + tile_lds_bytes(kTM, bpt, true);
+}
+
+// W [Dm, K] (nn.Linear layout) -> Wt [Kpad, DmPad], zero padded; 32x32 LDS-tiled transpose.
+__global__ __launch_bounds__(kThreads) void transpose_pad_kernel(const float *__restrict__ W, int Dm, int K,
+                                                                 float *__restrict__ Wt, int Kpad, int DmPad) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int k0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, k = k0 + tx;
+        tile[r][tx] = (j < Dm && k < K) ? W[(int64_t)j * K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, j = j0 + tx;
+        if (k < Kpad && j < DmPad) Wt[(int64_t)k * DmPad + j] = tile[tx][r];
+    }
+}
+
+template <int NT, int kBK>
+__global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const LinArgs P) {
+    constexpr int WP = kBK * NT / 8;  // float4 of the W chunk per thread
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+    const MixArgs &A = P.M;
+    const int bpt = A.bpt, sv = bpt | 1, SS = 1 + bpt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    LinLds S;
+    {
+        float *f = (float *)lds;
+        S.W0 = f; f += 2 * kBK * P.DmPad;
+        S.A0 = f; f += 2 * kBK * kTM;
+        S.scale = f; f += kTM * SS;
+        S.rowss = f; f += 4 * kTM;
+        S.tokc = (int32_t *)f; f += kTM;
+        size_t used = (size_t)(f - (float *)lds);
+        used = (used + 3) & ~(size_t)3;
+        S.tile = tile_lds_carve(lds + used, kTM, bpt, true);
+    }
+    const TileLds &L = S.tile;
+    const int64_t row = blockIdx.x / A.tiles_per_row;
+    const int64_t t0 = (int64_t)(blockIdx.x % A.tiles_per_row) * kTM;
+    const int ntok = (int)min((int64_t)kTM, A.T - t0);
+
+    // ---- phase 1: byte ids of the tile
+    if (A.id_source == MOT_IDS_FROM_TTB) {
+        if (A.pull_dir == kPullLeft) phase1_from_ttb<kPullLeft>(A, L, row, t0, ntok);
+        else if (A.pull_dir == kPullRight) phase1_from_ttb<kPullRight>(A, L, row, t0, ntok);
+        else phase1_from_ttb<kPullNone>(A, L, row, t0, ntok);
+    } else {
+        phase1_given(A, L, row, t0, ntok);
+    }
+
+    // ---- per-segment rms factors (rms_norm of a segment = raw * r: folded into the A operand)
+    for (int i = tid; i < kTM * SS; i += kThreads) S.scale[i] = 1.0f;
+    if (tid < kTM) {
+        int tok = tid < ntok ? L.tok[tid] : 0;
+        if ((uint64_t)(uint32_t)tok >= (uint64_t)A.tok_rows) {
+            if (A.status) atomicOr(A.status, kStatusTokenOor);
+            tok = 0;
+        }
+        S.tokc[tid] = tok;
+    }
+    __syncthreads();
+    if (A.norm_tok) {
+        for (int t = wave; t < ntok; t += kWaves) {
+            const float *trow = A.tok_table + (int64_t)S.tokc[t] * A.Dt;
+            float ss = 0.f;
+            for (int c = lane; c < (A.Dt >> 2); c += 64) {
+                const float4v v = *(const float4v *)(trow + 4 * c);
+                ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+            ss = wave_sum(ss);
+            if (lane == 0) S.scale[t * SS] = rms_scale(ss, A.Dt, A.eps);
+        }
+    }
+    if (A.norm_byte) {
+        for (int p = tid; p < ntok * bpt; p += kThreads) {
+            const int t = p / bpt, k = p - t * bpt;
+            const int id = L.ids[t * sv + k];
+            float r;
+            if (!P.dual) {
+                r = A.byte_rnorm[id];
+            } else {  // norm(emb(padded) + emb(pulled)), train_gpt.py:378
+                const int id2 = L.val[t * sv + k];
+                const float *pa = A.byte_table + (int64_t)id * A.Db, *pb = A.byte_table + (int64_t)id2 * A.Db;
+                float ss = 0.f;
+                for (int j = 0; j < A.Db; j += 4) {
+                    const float4v v = *(const float4v *)(pa + j) + *(const float4v *)(pb + j);
+                    ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+                r = rms_scale(ss, A.Db, A.eps);
+            }
+            S.scale[t * SS + 1 + k] = r;
+        }
+    }
+    __syncthreads();
+
+    // ---- K loop
+    const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
+    const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
+    const bool scale_t = A.scale_tok != nullptr, scale_b = A.scale_byte != nullptr;
+    const int am = tid & 63, akq = tid >> 6;  // A staging role: token am, float4 akq of the 16-wide step
+    const int nbytes_k = bpt * A.Db;
+    float4v wreg[WP], areg;
+
+    auto load_stage = [&](int s) {
+        const int k0 = s * kBK;
+        const float4v *src = (const float4v *)(P.Wt + (int64_t)k0 * P.DmPad);
+#pragma unroll
+        for (int p = 0; p < WP; ++p) wreg[p] = src[p * kThreads + tid];
+        const int k = k0 + 4 * akq;
+        areg = (float4v)(0.f);
+        if (akq < kBK / 4 && am < ntok && k < P.K) {
+            int slot = -1, off;
+            if (!P.bytes_first) {
+                if (k < A.Dt) off = k;
+                else { const int kb = k - A.Dt; slot = kb / A.Db; off = kb - slot * A.Db; }
+            } else {
+                if (k < nbytes_k) { slot = k / A.Db; off = k - slot * A.Db; }
+                else off = k - nbytes_k;
+            }
+            if (slot < 0) {
+                float4v v = *(const float4v *)(A.tok_table + (int64_t)S.tokc[am] * A.Dt + off);
+                v *= S.scale[am * SS];
+                if (scale_t) v *= s_tok;
+                areg = v;
+            } else {
+                float4v v = *(const float4v *)(A.byte_table + (int64_t)L.ids[am * sv + slot] * A.Db + off);
+                if (P.dual) v += *(const float4v *)(A.byte_table + (int64_t)L.val[am * sv + slot] * A.Db + off);
+                v *= S.scale[am * SS + 1 + slot];
+                if (scale_b) v *= s_byte;
+                areg = v;
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        float4v *dst = (float4v *)(S.W0 + buf * (kBK * P.DmPad));
+#pragma unroll
+        for (int p = 0; p < WP; ++p) dst[p * kThreads + tid] = wreg[p];
+        if (akq < kBK / 4) {
+            float *a = S.A0 + buf * (kBK * kTM) + (4 * akq) * kTM + am;  // k-major: A[k][m]
+            a[0] = areg.x; a[kTM] = areg.y; a[2 * kTM] = areg.z; a[3 * kTM] = areg.w;
+        }
+    };
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int h = lane >> 5, li = lane & 31;
+    const int n0 = wave * (NT * 32);
+    const int nsteps = P.Kpad / kBK;
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const bool more = s + 1 < nsteps;
+        if (more) load_stage(s + 1);
+        const float *Ab = S.A0 + (s & 1) * (kBK * kTM), *Wb = S.W0 + (s & 1) * (kBK * P.DmPad);
+#pragma unroll
+        for (int kk = 0; kk < kBK; kk += 2) {
+            // v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]
+            const float a0 = Ab[(kk + h) * kTM + li], a1 = Ab[(kk + h) * kTM + 32 + li];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const float b = Wb[(kk + h) * P.DmPad + n0 + nt * 32 + li];
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][nt], 0, 0, 0);
+            }
+        }
+        if (more) store_stage((s + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    if (P.bias) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + nt * 32 + li;
+            const float bv = col < P.Dm ? P.bias[col] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bv;
+        }
+    }
+    if (A.norm_out) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float ss = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) ss += acc[mt][nt][r] * acc[mt][nt][r];  // padded columns hold 0
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);  // stays inside the 32-lane half
+                if (li == 0) S.rowss[wave * kTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = ss;
+            }
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float tot = ((S.rowss[m] + S.rowss[kTM + m]) + S.rowss[2 * kTM + m]) + S.rowss[3 * kTM + m];
+                const float rs = rms_scale(tot, P.Dm, A.eps);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] *= rs;
+            }
+    }
+    float *orow = A.out + (row * A.T + t0) * (int64_t)P.Dm;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < ntok) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int col = n0 + nt * 32 + li;
+                    if (col < P.Dm) __builtin_nontemporal_store(acc[mt][nt][r], orow + (int64_t)m * P.Dm + col);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+static int nt_of(int Dm) {
+    const int nt = (Dm + 127) / 128;
+    if (nt <= 4) return nt;
+    if (nt <= 6) return 6;
+    if (nt <= 8) return 8;
+    return -1;
+}
+
+size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d) {
+    const int nt = nt_of(d.model_dim);
+    if (nt < 0) return 0;
+    const int K = d.tok_dim + d.bpt * d.byte_dim;
+    const size_t Kpad = (size_t)(K + kBKmax - 1) / kBKmax * kBKmax, DmPad = (size_t)nt * 128;
+    return (Kpad * DmPad + (size_t)d.byte_rows) * sizeof(float);
+}
+
+template <int NT, int BK>
+static int launch_lin(const LinArgs &P, int64_t blocks, hipStream_t stream) {
+    const size_t lds = lin_lds_bytes(P.DmPad, P.M.bpt, BK);
+    if (lds > 160 * 1024)
+        return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: needs %zu B of LDS (model_dim %d, bpt %d) > 160 KiB", lds, P.Dm, P.M.bpt);
+    static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent; a race sets it twice at worst
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_kernel<NT, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_linear_kernel): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((embed_mix_linear_kernel<NT, BK>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, P);
+    return check_launch("embed_mix_linear_kernel");
+}
+
+int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) {
+    const int nt = nt_of(d.model_dim);
+    if (nt < 0) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: model_dim %d > 1024 is not built", d.model_dim);
+    if ((d.tok_dim & 3) || (d.byte_dim & 3))
+        return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: tok_dim/byte_dim must be multiples of 4 (got %d, %d)", d.tok_dim, d.byte_dim);
+    LinArgs P;
+    fill_mix_args(P.M, d);
+    P.K = d.tok_dim + d.bpt * d.byte_dim;
+    P.Kpad = (P.K + kBKmax - 1) / kBKmax * kBKmax;
+    P.Dm = d.model_dim;
+    P.DmPad = nt * 128;
+    P.bytes_first = d.bytes_first;
+    P.dual = d.id_source == MOT_IDS_FROM_TTB ? d.add_padded != 0 : d.ids_b != nullptr;
+    P.bias = (const float *)d.bias;
+    const size_t need = embed_mix_linear_workspace_bytes(d);
+    if (!d.workspace || d.workspace_bytes < need)
+        return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
+    float *Wt = (float *)d.workspace;
+    float *rn = Wt + (size_t)P.Kpad * P.DmPad;
+    P.Wt = Wt;
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((P.Kpad + 31) / 32), (unsigned)((P.DmPad + 31) / 32)),
+                       dim3(kThreads), 0, stream, (const float *)d.weight, P.Dm, P.K, Wt, P.Kpad, P.DmPad);
+    int rc = check_launch("transpose_pad_kernel");
+    if (rc) return rc;
+    if (d.norm_byte && !P.dual) {
+        rc = launch_rows_rnorm(P.M.byte_table, d.byte_rows, d.byte_dim, P.M.eps, rn, stream);
+        if (rc) return rc;
+        P.M.byte_rnorm = rn;
+    }
+    P.M.tile_tokens = kTM;
+    const int64_t tiles_per_row = (d.tokens_per_row + kTM - 1) / kTM;
+    P.M.tiles_per_row = (int)tiles_per_row;
+    const int64_t blocks = d.n_rows * tiles_per_row;
+    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: too many tiles");
+    switch (nt) {
+        case 1: return launch_lin<1, 16>(P, blocks, stream);
+        case 2: return launch_lin<2, 16>(P, blocks, stream);
+        case 3: return launch_lin<3, 16>(P, blocks, stream);
+        case 4: return launch_lin<4, 16>(P, blocks, stream);
+        case 6: return launch_lin<6, 16>(P, blocks, stream);
+        default: return launch_lin<8, 8>(P, blocks, stream);
+    }
 }
 
 }  // namespace mot
