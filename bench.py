@@ -36,7 +36,11 @@ WORKLOADS = {
     "c4": (256, 2048, 50257, 16, 768, 48, 458, "sum"),     # headline: BASELINE configs[3]
     "c2": (64, 1024, 50257, 16, 768, 48, 458, "sum"),      # configs[1]
     "c5": (64, 8192, 128256, 8, 2048, 2048, 132, "mean"),  # configs[4] shape family, quarter batch
+    # concat + linear mixin (MFMA-bound): (.., d_model, byte_dim, .., mode, token_dim)
+    "c2l": (64, 1024, 50257, 16, 768, 32, 458, "concat_linear", 256),     # configs[1] CONCAT dims (K = 768)
+    "prodl": (64, 1024, 50257, 16, 1024, 48, 458, "concat_linear", 256),  # experiments100_000steps.sh dims (K = 1024)
 }
+F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak, MI355X_MICROARCH.md
 
 
 def parse():
@@ -55,11 +59,12 @@ def parse():
 
 def make_inputs(wl, device, seed, uniform):
     import golden_inputs as gi
-    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
+    Dt = WORKLOADS[wl][8] if mode == "concat_linear" else D
     g = torch.Generator(device=device).manual_seed(seed)
-    tok_table = torch.randn((vocab, D), generator=g, device=device, dtype=torch.float32)
+    tok_table = torch.randn((vocab, Dt), generator=g, device=device, dtype=torch.float32)
     byte_table = torch.randn((Vb, Db), generator=g, device=device, dtype=torch.float32)
-    if mode == "sum":
+    if mode in ("sum", "concat_linear"):
         try:
             tab = gi.widen_left_pad(gi.load_real_ttb8(), bpt)     # real GPT-2 token->char table (data fixture)
             ttb_kind = "gpt2 ttb_8_left_pad widened to 16"
@@ -67,7 +72,12 @@ def make_inputs(wl, device, seed, uniform):
             tab = gi.synth_ttb(5, vocab, bpt, "left")
             ttb_kind = "synthetic"
         toks = gi.fineweb_like_tokens(seed, B, T, vocab=vocab, uniform=uniform)
-        return dict(toks=toks, tab=tab, tok_table=tok_table, byte_table=byte_table, ttb_kind=ttb_kind)
+        weight = None
+        if mode == "concat_linear":
+            K = Dt + bpt * Db
+            bound = (3 ** 0.5) * 0.5 * K ** -0.5       # CastedLinear init, train_gpt.py:179-183
+            weight = (torch.rand((D, K), generator=g, device=device, dtype=torch.float32) * 2 - 1) * bound
+        return dict(toks=toks, tab=tab, tok_table=tok_table, byte_table=byte_table, ttb_kind=ttb_kind, weight=weight)
     rs = np.random.RandomState(seed)
     toks = rs.randint(0, vocab, size=(B, T)).astype(np.int32)
     chars = rs.randint(0, Vb, size=(B, T * bpt)).astype(np.int64)
@@ -76,8 +86,10 @@ def make_inputs(wl, device, seed, uniform):
 
 def algorithmic_bytes_per_token(wl, ids_mode):
     """fully fused R = 4 + 2*bpt + e*Dt, W = e*Dm; module-level path reads int64 ids."""
-    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
     e = 4
+    if mode == "concat_linear":
+        return 4 + 2 * bpt + e * WORKLOADS[wl][8] + e * D
     if mode == "sum":
         r = 4 + (2 * bpt if ids_mode == "fused" else 8 * bpt) + e * D
     else:
@@ -103,7 +115,7 @@ def cpu_baseline(wl, inp, seconds):
     gather/sum/rms-norm in fp32 on rows of the same workload, repeated for ~`seconds`."""
     from oracle import oracle as orc
     import golden_inputs as gi
-    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
     cores = usable_cores()
     orc.set_threads(cores)
     Et, Eb = inp["tok_table"].cpu().numpy(), inp["byte_table"].cpu().numpy()
@@ -115,6 +127,11 @@ def cpu_baseline(wl, inp, seconds):
             padded = orc.tokens_to_bytes(toks, inp["tab"].astype(np.float32))
             pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
             orc.embed_mix(toks, pulled, None, Et, Eb, mode="sum", bpt=bpt, dtype=np.float32, norm_out=True)
+        elif mode == "concat_linear":
+            padded = orc.tokens_to_bytes(toks, inp["tab"].astype(np.float32))
+            pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+            orc.embed_mix(toks, pulled, None, Et, Eb, mode="concat_linear", bpt=bpt, weight=inp["weight"].cpu().numpy(),
+                          dtype=np.float32, norm_tok=True, norm_byte=True, norm_out=True)
         else:
             orc.embed_mix(toks, inp["chars"][:rows], None, Et, Eb, mode="mean", bpt=bpt, dtype=np.float32)
 
@@ -147,7 +164,7 @@ def main():
 
     import mixture_of_tokenizers_amd as mot
     wl = args.workload
-    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl]
+    B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
     inp = make_inputs(wl, device, seed=12345 + rank, uniform=args.uniform_ids)   # loader default seed, train_gpt.py:661
     toks = torch.from_numpy(inp["toks"]).to(device)
     out = torch.empty((B, T, D), dtype=torch.float32, device=device)
@@ -165,6 +182,12 @@ def main():
             def step(cnt=None):
                 mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="sum", bpt=bpt, ids_a=ids, norm_out=True,
                               out=out, counters=cnt)
+    elif mode == "concat_linear":
+        tab = torch.from_numpy(inp["tab"]).to(device)
+
+        def step(cnt=None):
+            mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="concat_linear", bpt=bpt, ttb=tab, pull="left",
+                          weight=inp["weight"], norm_tok=True, norm_byte=True, norm_out=True, out=out, counters=cnt)
     else:
         chars = torch.from_numpy(inp["chars"]).to(device)
         lt, lc = torch.tensor(1.0, device=device), torch.tensor(0.5, device=device)
@@ -239,6 +262,12 @@ def main():
                            "mean_valid_per_token": (c[1] - c[2]) / max(c[0], 1),
                            "pulled_fill": (c[2] - c[3]) / max(c[1], 1)},
         }
+        if mode == "concat_linear":   # dense contraction: priced against the fp32 matrix peak, not HBM
+            K = WORKLOADS[wl][8] + bpt * Db
+            tf = 2.0 * K * D * tokens_per_step / (kernel_ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "embed_mix_linear_kernel",
+                               "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, inp, args.cpu_seconds)
         print(json.dumps(res), flush=True)

@@ -24,7 +24,6 @@ namespace mot {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTM = 64;  // tokens per workgroup tile
 constexpr int kBKmax = 16;  // K-step is 16 (8 for the widest accumulator tile, to stay inside 512 registers)
 
 struct LinArgs {
@@ -40,13 +39,13 @@ struct LinLds {
     TileLds tile;
 };
 
-__host__ __device__ inline size_t lin_lds_floats_before_tile(int DmPad, int bpt, int bk) {
-    return 2 * (size_t)bk * DmPad + 2 * (size_t)bk * kTM + (size_t)kTM * (1 + bpt) + 4 * kTM + kTM;
+__host__ __device__ inline size_t lin_lds_floats_before_tile(int DmPad, int bpt, int bk, int tm) {
+    return 2 * (size_t)bk * DmPad + 2 * (size_t)bk * tm + (size_t)tm * (1 + bpt) + 4 * tm + tm;
 }
-__host__ __device__ inline size_t lin_lds_bytes(int DmPad, int bpt, int bk) {
-    size_t f = lin_lds_floats_before_tile(DmPad, bpt, bk);
+__host__ __device__ inline size_t lin_lds_bytes(int DmPad, int bpt, int bk, int tm) {
+    size_t f = lin_lds_floats_before_tile(DmPad, bpt, bk, tm);
     f = (f + 3) & ~(size_t)3;
-    return f * 4 + tile_lds_bytes(kTM, bpt, true);
+    return f * 4 + tile_lds_bytes(tm, bpt, true);
 }
 
 // W [Dm, K] (nn.Linear layout) -> Wt [Kpad, DmPad], zero padded; 32x32 LDS-tiled transpose.
@@ -66,8 +65,10 @@ __global__ __launch_bounds__(kThreads) void transpose_pad_kernel(const float *__
     }
 }
 
-template <int NT, int kBK>
+// MT x NT accumulator tiles of 32x32 per wave: the workgroup tile is kTM = 32*MT tokens x 128*NT columns.
+template <int MT, int NT, int kBK>
 __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const LinArgs P) {
+    constexpr int kTM = 32 * MT;
     constexpr int WP = kBK * NT / 8;  // float4 of the W chunk per thread
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     const MixArgs &A = P.M;
@@ -148,53 +149,49 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const Lin
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     const bool scale_t = A.scale_tok != nullptr, scale_b = A.scale_byte != nullptr;
-    const int am = tid & 63, akq = tid >> 6;  // A staging role: token am, float4 akq of the 16-wide step
+    const int am = tid % kTM, akq = tid / kTM;  // A staging role: token am, float4 (akq mod kBK/4) of the K-step
     const int nbytes_k = bpt * A.Db;
     float4v wreg[WP], areg;
 
+    // Rows past the tile's end read token/byte id 0 (valid memory; never stored); K-padding columns
+    // meet zero rows of Wt.  Branch-free on purpose: the K loop body must stay one basic block so
+    // that the scheduler can overlap the partial-sum adds with the next tile's MFMAs.
+    const int amr = min(am, ntok - 1);  // row used for every lookup: always a real token of the tile
+    const int tok_m = S.tokc[amr];
     auto load_stage = [&](int s) {
         const int k0 = s * kBK;
         const float4v *src = (const float4v *)(P.Wt + (int64_t)k0 * P.DmPad);
 #pragma unroll
         for (int p = 0; p < WP; ++p) wreg[p] = src[p * kThreads + tid];
-        const int k = k0 + 4 * akq;
-        areg = (float4v)(0.f);
-        if (akq < kBK / 4 && am < ntok && k < P.K) {
-            int slot = -1, off;
-            if (!P.bytes_first) {
-                if (k < A.Dt) off = k;
-                else { const int kb = k - A.Dt; slot = kb / A.Db; off = kb - slot * A.Db; }
-            } else {
-                if (k < nbytes_k) { slot = k / A.Db; off = k - slot * A.Db; }
-                else off = k - nbytes_k;
-            }
-            if (slot < 0) {
-                float4v v = *(const float4v *)(A.tok_table + (int64_t)S.tokc[am] * A.Dt + off);
-                v *= S.scale[am * SS];
-                if (scale_t) v *= s_tok;
-                areg = v;
-            } else {
-                float4v v = *(const float4v *)(A.byte_table + (int64_t)L.ids[am * sv + slot] * A.Db + off);
-                if (P.dual) v += *(const float4v *)(A.byte_table + (int64_t)L.val[am * sv + slot] * A.Db + off);
-                v *= S.scale[am * SS + 1 + slot];
-                if (scale_b) v *= s_byte;
-                areg = v;
-            }
+        const int k = min(k0 + 4 * (akq & (kBK / 4 - 1)), P.K - 4);
+        const bool is_tok = P.bytes_first ? k >= nbytes_k : k < A.Dt;
+        const int kb = P.bytes_first ? k : k - A.Dt;             // offset inside the byte part
+        const int slot = is_tok ? 0 : kb / A.Db;
+        const int off = is_tok ? (P.bytes_first ? k - nbytes_k : k) : kb - slot * A.Db;
+        const int id1 = L.ids[amr * sv + slot];
+        const float *p1 = is_tok ? A.tok_table + (int64_t)tok_m * A.Dt + off : A.byte_table + (int64_t)id1 * A.Db + off;
+        float4v v = *(const float4v *)p1;
+        if (P.dual) {
+            const float4v v2 = *(const float4v *)(A.byte_table + (int64_t)L.val[amr * sv + slot] * A.Db + off);
+            v += is_tok ? (float4v)(0.f) : v2;
         }
+        v *= S.scale[amr * SS + (is_tok ? 0 : 1 + slot)];
+        const float sc = is_tok ? s_tok : s_byte;
+        if (is_tok ? scale_t : scale_b) v *= sc;
+        areg = v;
     };
     auto store_stage = [&](int buf) {
         float4v *dst = (float4v *)(S.W0 + buf * (kBK * P.DmPad));
 #pragma unroll
         for (int p = 0; p < WP; ++p) dst[p * kThreads + tid] = wreg[p];
-        if (akq < kBK / 4) {
-            float *a = S.A0 + buf * (kBK * kTM) + (4 * akq) * kTM + am;  // k-major: A[k][m]
-            a[0] = areg.x; a[kTM] = areg.y; a[2 * kTM] = areg.z; a[3 * kTM] = areg.w;
-        }
+        // k-major A[k][m]; with kBK == 8 waves 2-3 duplicate the writes of waves 0-1 (same values)
+        float *a = S.A0 + buf * (kBK * kTM) + (4 * (akq & (kBK / 4 - 1))) * kTM + am;
+        a[0] = areg.x; a[kTM] = areg.y; a[2 * kTM] = areg.z; a[3 * kTM] = areg.w;
     };
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -202,26 +199,49 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const Lin
 
     const int h = lane >> 5, li = lane & 31;
     const int n0 = wave * (NT * 32);
+    f32x16 zero16;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
     const int nsteps = P.Kpad / kBK;
     load_stage(0);
     store_stage(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
-        const bool more = s + 1 < nsteps;
-        if (more) load_stage(s + 1);
+        load_stage(min(s + 1, nsteps - 1));  // the last step re-loads itself: keeps the body branch-free
         const float *Ab = S.A0 + (s & 1) * (kBK * kTM), *Wb = S.W0 + (s & 1) * (kBK * P.DmPad);
+        // v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
+        // Blocked summation: the kBK products of this step are chained in a fresh accumulator and
+        // that partial sum is added to the running one, so the long chain has K/kBK terms instead
+        // of K (a single K-long fp32 chain is ~2x less accurate than the reference's blocked sgemm).
+        float af[MT][kBK / 2];
 #pragma unroll
-        for (int kk = 0; kk < kBK; kk += 2) {
-            // v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]
-            const float a0 = Ab[(kk + h) * kTM + li], a1 = Ab[(kk + h) * kTM + 32 + li];
+        for (int kp = 0; kp < kBK / 2; ++kp)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float b = Wb[(kk + h) * P.DmPad + n0 + nt * 32 + li];
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[1][nt], 0, 0, 0);
+            for (int mt = 0; mt < MT; ++mt) af[mt][kp] = Ab[(2 * kp + h) * kTM + mt * 32 + li];
+        // Software pipeline over the 2*NT accumulator tiles: tile j's kBK/2 chained MFMAs run while
+        // the VALU adds tile j-1's finished partial sum into the running accumulator.
+        f32x16 prev = zero16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float bf[kBK / 2];
+#pragma unroll
+            for (int kp = 0; kp < kBK / 2; ++kp) bf[kp] = Wb[(2 * kp + h) * P.DmPad + n0 + nt * 32 + li];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                f32x16 part = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][0], bf[0], zero16, 0, 0, 0);
+#pragma unroll
+                for (int kp = 1; kp < kBK / 2; ++kp) part = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][kp], bf[kp], part, 0, 0, 0);
+                if (nt > 0 || mt > 0) acc[(mt + MT - 1) % MT][mt == 0 ? nt - 1 : nt] += prev;  // the previous tile
+                prev = part;
+#pragma unroll
+                for (int kp = 0; kp < kBK / 2; ++kp) {  // per MFMA: a few of the previous tile's adds
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 48 / (kBK / 2), 0);
+                }
             }
         }
-        if (more) store_stage((s + 1) & 1);
+        acc[MT - 1][NT - 1] += prev;
+        store_stage((s + 1) & 1);
         __syncthreads();
     }
 
@@ -232,14 +252,14 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const Lin
             const int col = n0 + nt * 32 + li;
             const float bv = col < P.Dm ? P.bias[col] : 0.f;
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bv;
         }
     }
     if (A.norm_out) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float ss = 0.f;
@@ -251,7 +271,7 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const Lin
             }
         __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const Lin
     }
     float *orow = A.out + (row * A.T + t0) * (int64_t)P.Dm;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -294,18 +314,24 @@ size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d) {
     return (Kpad * DmPad + (size_t)d.byte_rows) * sizeof(float);
 }
 
-template <int NT, int BK>
-static int launch_lin(const LinArgs &P, int64_t blocks, hipStream_t stream) {
-    const size_t lds = lin_lds_bytes(P.DmPad, P.M.bpt, BK);
+template <int MT, int NT, int BK>
+static int launch_lin(LinArgs &P, const MotEmbedMixDesc &d, hipStream_t stream) {
+    constexpr int TM = 32 * MT;
+    P.M.tile_tokens = TM;
+    const int64_t tiles_per_row = (d.tokens_per_row + TM - 1) / TM;
+    P.M.tiles_per_row = (int)tiles_per_row;
+    const int64_t blocks = d.n_rows * tiles_per_row;
+    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: too many tiles");
+    const size_t lds = lin_lds_bytes(P.DmPad, P.M.bpt, BK, TM);
     if (lds > 160 * 1024)
         return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: needs %zu B of LDS (model_dim %d, bpt %d) > 160 KiB", lds, P.Dm, P.M.bpt);
     static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent; a race sets it twice at worst
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_kernel<NT, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_kernel<MT, NT, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_linear_kernel): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_mix_linear_kernel<NT, BK>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, P);
+    hipLaunchKernelGGL((embed_mix_linear_kernel<MT, NT, BK>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, P);
     return check_launch("embed_mix_linear_kernel");
 }
 
@@ -338,18 +364,15 @@ int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) {
         if (rc) return rc;
         P.M.byte_rnorm = rn;
     }
-    P.M.tile_tokens = kTM;
-    const int64_t tiles_per_row = (d.tokens_per_row + kTM - 1) / kTM;
-    P.M.tiles_per_row = (int)tiles_per_row;
-    const int64_t blocks = d.n_rows * tiles_per_row;
-    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: too many tiles");
+    // 64-token tiles while the accumulators (2*NT*16 registers) leave room for the partial sums in the
+    // 256 architectural VGPRs; the 1024-column variant runs 32-token tiles instead.
     switch (nt) {
-        case 1: return launch_lin<1, 16>(P, blocks, stream);
-        case 2: return launch_lin<2, 16>(P, blocks, stream);
-        case 3: return launch_lin<3, 16>(P, blocks, stream);
-        case 4: return launch_lin<4, 16>(P, blocks, stream);
-        case 6: return launch_lin<6, 16>(P, blocks, stream);
-        default: return launch_lin<8, 8>(P, blocks, stream);
+        case 1: return launch_lin<2, 1, 16>(P, d, stream);
+        case 2: return launch_lin<2, 2, 16>(P, d, stream);
+        case 3: return launch_lin<2, 3, 16>(P, d, stream);
+        case 4: return launch_lin<2, 4, 16>(P, d, stream);
+        case 6: return launch_lin<2, 6, 16>(P, d, stream);
+        default: return launch_lin<1, 8, 16>(P, d, stream);
     }
 }
 
