@@ -1,0 +1,389 @@
+"""``nn.Module`` boundary of the embedding front-end: the reference's own classes for this path,
+same constructor arguments, attribute names, state-dict keys and ``forward`` signatures, with the
+work done by the fused HIP kernels.
+
+scaled-pre-train (train_gpt.py):  ByteHyperparameters, ModelDims (146-169), norm (172-173),
+    CastedLinear (175-186), FlexibleEmbedding (327-379), ByteMixinNoop / ByteMixinConcat /
+    ByteMixin (421-443, 467-480); call site ``xt, xb = self.embed(...); x = self.byte_mixin(xt, xb)``
+    (605-606) works unchanged.
+mathblations (model.py):  GPTConfig (16-29), DigitMixinConcat / DigitMixinNoOp / make_digit_mixin
+    (256-284), and the ``wte`` / ``dte`` / ``digit_mixin`` triple of GPT (304-306, 323-327).
+modded-nanogpt (runs/71*.py):  the SUM mixin ``norm(embed_tokens(tok) + concat_k embed_bytes(b_k))``
+    (227-230, 312-314) and its per-embedding-norm / lambda variants (runs/71041, 71081).
+
+Fusion across the two-module seam: ``FlexibleEmbedding.forward`` (and ``LazyEmbedding.forward``)
+return an :class:`EmbedHandle` -- ids plus references to the live Parameters -- instead of
+materialised (B,T,D) tensors; the mixin's ``forward`` launches ONE kernel that gathers, normalises,
+mixes and writes x.  Anything that needs the tensors themselves calls ``handle.materialize()``.
+Parameters are read from their live storage at launch time, so weight tying
+(``wte.weight = lm_head.weight``, model.py:316-317) and in-place optimizer updates are honoured.
+
+Forward only (backward is the next row): calling these modules with autograd
+enabled on parameters that require grad raises instead of silently dropping the graph.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Literal
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import functional as F_mot
+from .data_creation import _table_of
+
+
+# ------------------------------------------------------------------------------------------------
+# configuration dataclasses (field-for-field the reference's)
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ByteHyperparameters:  # train_gpt.py:146-161
+    bytes_per_token: int = 16
+    vocab_size: int = 458
+    byte_mixin_method: Literal["cross_attn", "concat", "noop"] = "noop"
+    byte_mixout_method: Literal["noop", "copy", "split"] = "noop"
+    use_byte_self_attn: bool = False
+    padding_in: Literal["left", "right"] = "left"
+    padding_out: Literal["left", "right"] = "left"
+    pull_in: bool = True
+    pull_out: bool = True
+    add_padded_and_pulled: bool = False
+    sliding_window_tokens: int = 8
+    n_layer_out: int = 1
+    mix_bytes_within_tok_in: bool = False
+    mix_bytes_within_tok_out: bool = False
+
+
+@dataclass
+class ModelDims:  # train_gpt.py:164-169
+    model_dim: int = 768
+    byte_dim: int = 768
+    token_dim: int = 768
+    expansion_factor: float = 4.0
+
+
+@dataclass
+class GPTConfig:  # mathblations/model.py:16-29
+    vocab_size: int = 50304
+    n_layer: int = 12
+    n_head: int = 6
+    n_embd_tok: int = 768
+    n_embd_digit: int = 768
+    T: int = 1024
+    length_factor: int = 3
+    k_gt_q: bool = True
+    n_layer_output: int = 1
+    digit_mixout_method: Literal["self_attn", "cross_attn", "noop"] = "noop"
+    digit_mixin_method: Literal["cross_attn", "concat", "noop"] = "noop"
+    use_digit_self_attn: bool = False
+
+
+def norm(x: Tensor) -> Tensor:
+    """train_gpt.py:172-173 (a plain torch op: the trunk calls it on arbitrary activations)."""
+    return F.rms_norm(x, (x.size(-1),))
+
+
+class CastedLinear(nn.Linear):  # train_gpt.py:175-186
+    def __init__(self, in_features: int, out_features: int):
+        super().__init__(in_features, out_features, bias=False)
+
+    def reset_parameters(self) -> None:
+        std = 0.5 * (self.in_features ** -0.5)
+        bound = (3 ** 0.5) * std
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+
+    def forward(self, x: Tensor):
+        return F.linear(x, self.weight.type_as(x))
+
+
+# ------------------------------------------------------------------------------------------------
+# the handle that crosses the embed / mixin seam
+# ------------------------------------------------------------------------------------------------
+def _check_forward_only(*params) -> None:
+    if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
+        raise RuntimeError(
+            "mixture-of-tokenizers_amd implements the forward of the embedding front-end only (backward is the "
+            "next scope row); call it under torch.no_grad() or with frozen parameters")
+
+
+def _f32(p: Tensor, what: str) -> Tensor:
+    if p.dtype != torch.float32:
+        raise NotImplementedError(f"{what} is {p.dtype}: only the fp32 parity mode is built (bf16 tables are a later row)")
+    return p
+
+
+class EmbedHandle:
+    """What a fused embedding returns in place of its (B, T, D) output: the ids and the table."""
+
+    def __init__(self, *, tokens: Tensor | None = None, tok_weight: Tensor | None = None, norm_tok: bool = False,
+                 ids_a: Tensor | None = None, ids_b: Tensor | None = None, byte_weight: Tensor | None = None,
+                 norm_byte: bool = False, bpt: int = 0, scale_tok: Tensor | None = None, scale_byte: Tensor | None = None):
+        self.tokens, self.tok_weight, self.norm_tok = tokens, tok_weight, norm_tok
+        self.ids_a, self.ids_b, self.byte_weight, self.norm_byte, self.bpt = ids_a, ids_b, byte_weight, norm_byte, bpt
+        self.scale_tok, self.scale_byte = scale_tok, scale_byte
+
+    def merged(self, other: "EmbedHandle") -> "EmbedHandle":
+        """token-side handle + byte-side handle (mathblations: wte(idx), dte(digits))."""
+        return EmbedHandle(tokens=self.tokens, tok_weight=self.tok_weight, norm_tok=self.norm_tok,
+                           ids_a=other.ids_a, ids_b=other.ids_b, byte_weight=other.byte_weight,
+                           norm_byte=other.norm_byte, bpt=other.bpt, scale_tok=self.scale_tok, scale_byte=other.scale_byte)
+
+    def materialize(self) -> tuple[Tensor | None, Tensor | None]:
+        """(tok_embs (B,T,Dt) | None, byte_embs (B,T*bpt,Db) | None) exactly as the reference's
+        FlexibleEmbedding.forward returns them (train_gpt.py:342-379)."""
+        te = be = None
+        if self.tokens is not None:
+            te = F_mot.gather_rows(_f32(self.tok_weight, "token table"), self.tokens, rms_norm=self.norm_tok, scale=self.scale_tok)
+        if self.ids_a is not None:
+            be = F_mot.gather_rows(_f32(self.byte_weight, "byte table"), self.ids_a, self.ids_b, rms_norm=self.norm_byte,
+                                   scale=self.scale_byte)
+        return te, be
+
+
+# ------------------------------------------------------------------------------------------------
+# scaled-pre-train
+# ------------------------------------------------------------------------------------------------
+class FlexibleEmbedding(nn.Module):
+    """train_gpt.py:327-379.  ``fused=True`` (default) defers the gathers to the mixin's kernel."""
+
+    def __init__(self, dims: ModelDims, vocab_size, byte_params: ByteHyperparameters, fused: bool = True):
+        super().__init__()
+        noop = byte_params.byte_mixin_method == "noop"
+        self.embed_tokens = nn.Embedding(vocab_size, dims.token_dim if not noop else dims.model_dim)
+        self.embed_bytes = nn.Embedding(byte_params.vocab_size, dims.byte_dim) if not noop else nn.Identity()
+        self.byte_params = byte_params
+        self.fused = fused
+        if noop:
+            self._mode = "tokens"
+        elif not byte_params.pull_in:
+            self._mode = "padded"
+        elif not byte_params.add_padded_and_pulled:
+            self._mode = "pulled"
+        else:
+            self._mode = "padded_and_pulled"
+
+    def handle(self, tokens: Tensor, byte_tensor: Tensor | None, byte_tensor_pulled: Tensor | None) -> EmbedHandle:
+        bp = self.byte_params
+        if self._mode == "tokens":
+            return EmbedHandle(tokens=tokens, tok_weight=self.embed_tokens.weight, norm_tok=True)
+        ids_a, ids_b = {"padded": (byte_tensor, None), "pulled": (byte_tensor_pulled, None),
+                        "padded_and_pulled": (byte_tensor, byte_tensor_pulled)}[self._mode]
+        return EmbedHandle(tokens=tokens, tok_weight=self.embed_tokens.weight, norm_tok=True, ids_a=ids_a, ids_b=ids_b,
+                           byte_weight=self.embed_bytes.weight, norm_byte=True, bpt=bp.bytes_per_token)
+
+    def forward(self, tokens: Tensor, byte_tensor: Tensor | None, byte_tensor_pulled: Tensor | None):
+        h = self.handle(tokens, byte_tensor, byte_tensor_pulled)
+        if self.fused:
+            return h, None
+        _check_forward_only(self.embed_tokens.weight, getattr(self.embed_bytes, "weight", None))
+        return h.materialize()
+
+
+class ByteMixinNoop(nn.Module):  # train_gpt.py:421-427
+    def __init__(self, dims: ModelDims, max_seq_len: int, byte_params: ByteHyperparameters):
+        super().__init__()
+        self.attention = self.mixin = nn.Identity()
+
+    def forward(self, x, *args):
+        if isinstance(x, EmbedHandle):
+            _check_forward_only(x.tok_weight)
+            return F_mot.embed_mix(x.tokens, _f32(x.tok_weight, "token table"), mode="noop", norm_tok=x.norm_tok,
+                                   scale_tok=x.scale_tok)
+        return x
+
+
+def _mix_concat(h_or_tok, byte_embs, *, bpt: int, weight: Tensor, bias: Tensor | None, bytes_first: bool, norm_out: bool):
+    """Shared by ByteMixinConcat and DigitMixinConcat: fused when given a handle, otherwise the same
+    kernel over the already materialised seam tensors (rows addressed by arange ids)."""
+    if isinstance(h_or_tok, EmbedHandle):
+        h = h_or_tok
+        _check_forward_only(h.tok_weight, h.byte_weight, weight, bias)
+        return F_mot.embed_mix(h.tokens, _f32(h.tok_weight, "token table"), _f32(h.byte_weight, "byte table"),
+                               mode="concat_linear", bpt=h.bpt, ids_a=h.ids_a.reshape(h.tokens.shape[0], -1),
+                               ids_b=None if h.ids_b is None else h.ids_b.reshape(h.tokens.shape[0], -1),
+                               weight=_f32(weight, "mixin weight"), bias=bias, bytes_first=bytes_first,
+                               norm_tok=h.norm_tok, norm_byte=h.norm_byte, norm_out=norm_out,
+                               scale_tok=h.scale_tok, scale_byte=h.scale_byte)
+    tok_embs = h_or_tok
+    _check_forward_only(weight, bias)
+    if tok_embs.requires_grad or byte_embs.requires_grad:
+        _check_forward_only(tok_embs, byte_embs)
+    B, T, Dt = tok_embs.shape
+    Db = byte_embs.shape[-1]
+    dev = tok_embs.device
+    tok_rows = torch.arange(B * T, dtype=torch.int32, device=dev).view(B, T)
+    byte_rows = torch.arange(B * T * bpt, dtype=torch.int64, device=dev).view(B, T * bpt)
+    return F_mot.embed_mix(tok_rows, tok_embs.reshape(B * T, Dt), byte_embs.reshape(B * T * bpt, Db), mode="concat_linear",
+                           bpt=bpt, ids_a=byte_rows, weight=_f32(weight, "mixin weight"), bias=bias, bytes_first=bytes_first,
+                           norm_out=norm_out)
+
+
+class ByteMixinConcat(nn.Module):  # train_gpt.py:430-443
+    def __init__(self, dims: ModelDims, max_seq_len: int, byte_params: ByteHyperparameters):
+        super().__init__()
+        self.byte_params = byte_params
+        if byte_params.use_byte_self_attn:
+            raise NotImplementedError("use_byte_self_attn (ByteSelfAttn, train_gpt.py:382-418) is outside the front-end path")
+        self.attention = nn.Identity()
+        self.mixin = CastedLinear(dims.token_dim + dims.byte_dim * byte_params.bytes_per_token, dims.model_dim)
+
+    def forward(self, tok_embs, byte_embs=None) -> Tensor:
+        return _mix_concat(tok_embs, byte_embs, bpt=self.byte_params.bytes_per_token, weight=self.mixin.weight, bias=None,
+                           bytes_first=False, norm_out=True)
+
+
+class ByteMixin(nn.Module):  # train_gpt.py:467-480
+    def __init__(self, dims: ModelDims, max_seq_len: int, byte_params: ByteHyperparameters):
+        super().__init__()
+        if byte_params.byte_mixin_method == "noop":
+            self.mixin = ByteMixinNoop(dims, max_seq_len, byte_params)
+        elif byte_params.byte_mixin_method == "cross_attn":
+            raise NotImplementedError("byte_mixin_method='cross_attn' (train_gpt.py:446-464) is a later scope row")
+        elif byte_params.byte_mixin_method == "concat":
+            self.mixin = ByteMixinConcat(dims, max_seq_len, byte_params)
+        else:
+            raise RuntimeError(f"Invalid byte mixin method: {byte_params.byte_mixin_method}")
+
+    def forward(self, tok_embs, byte_embs=None) -> Tensor:
+        return self.mixin(tok_embs, byte_embs)
+
+
+class FusedFrontEnd(nn.Module):
+    """Loader + embed + mixin in one launch: tokens (B,T) -> x (B,T,model_dim), with the
+    token->byte gather and the pull done inside the kernel (byte ids never reach HBM).  Holds the
+    same submodules under the reference's names (``embed``, ``byte_mixin``), so a GPT can adopt its
+    parameters directly; the token->byte table is a non-persistent integer buffer."""
+
+    def __init__(self, dims: ModelDims, vocab_size: int, byte_params: ByteHyperparameters, ttb, max_seq_len: int = 1024,
+                 pad_byte: int = 456, eot_byte: int = 457):
+        super().__init__()
+        self.embed = FlexibleEmbedding(dims, vocab_size, byte_params, fused=True)
+        self.byte_mixin = ByteMixin(dims, max_seq_len, byte_params)
+        self.byte_params = byte_params
+        self.pad_byte, self.eot_byte = pad_byte, eot_byte
+        self.register_buffer("ttb", _table_of(ttb).clone() if ttb is not None else None, persistent=False)
+
+    def forward(self, tokens: Tensor, return_ids: bool = False):
+        bp, emb = self.byte_params, self.embed
+        if bp.byte_mixin_method == "noop":
+            return self.byte_mixin(*emb(tokens, None, None))
+        _check_forward_only(emb.embed_tokens.weight, emb.embed_bytes.weight, self.byte_mixin.mixin.mixin.weight)
+        pull = None if not bp.pull_in else bp.padding_in          # left-padded bytes are pulled from the left
+        return F_mot.embed_mix(tokens, _f32(emb.embed_tokens.weight, "token table"), _f32(emb.embed_bytes.weight, "byte table"),
+                               mode="concat_linear", bpt=bp.bytes_per_token, ttb=self.ttb, pull=pull,
+                               add_padded=bp.pull_in and bp.add_padded_and_pulled, pad_byte=self.pad_byte,
+                               eot_byte=self.eot_byte, weight=_f32(self.byte_mixin.mixin.mixin.weight, "mixin weight"),
+                               norm_tok=True, norm_byte=True, norm_out=True, return_ids=return_ids)
+
+
+# ------------------------------------------------------------------------------------------------
+# mathblations
+# ------------------------------------------------------------------------------------------------
+class LazyEmbedding(nn.Embedding):
+    """Drop-in for ``GPT.wte`` / ``GPT.dte`` (model.py:304-305): forward returns an EmbedHandle that
+    ``digit_mixin`` consumes; ``.weight`` stays an ordinary Parameter and may be tied (model.py:314-317)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, role: Literal["tokens", "bytes"] = "tokens", slots: int = 0):
+        super().__init__(num_embeddings, embedding_dim)
+        self.role, self.slots = role, slots
+
+    def forward(self, ids: Tensor) -> EmbedHandle:  # type: ignore[override]
+        if self.role == "tokens":
+            return EmbedHandle(tokens=ids, tok_weight=self.weight)
+        return EmbedHandle(ids_a=ids, byte_weight=self.weight, bpt=self.slots)
+
+
+class DigitMixinConcat(nn.Module):  # model.py:256-268
+    def __init__(self, config: GPTConfig):
+        super().__init__()
+        self.config = config
+        if config.use_digit_self_attn:
+            raise NotImplementedError("use_digit_self_attn (model.py:260,264-265) is outside the front-end path")
+        self.digit_attn = nn.Identity()
+        self.fc = nn.Linear(config.n_embd_tok + config.n_embd_digit * config.length_factor, config.n_embd_tok)
+
+    def forward(self, we, de):
+        if isinstance(we, EmbedHandle) and isinstance(de, EmbedHandle):
+            we = we.merged(de)
+            we.bpt = self.config.length_factor
+            de = None
+        elif isinstance(we, EmbedHandle) or isinstance(de, EmbedHandle):
+            we = we.materialize()[0] if isinstance(we, EmbedHandle) else we
+            de = de.materialize()[1] if isinstance(de, EmbedHandle) else de
+        return _mix_concat(we, de, bpt=self.config.length_factor, weight=self.fc.weight, bias=self.fc.bias, bytes_first=True,
+                           norm_out=False)
+
+
+class DigitMixinNoOp(nn.Module):  # model.py:271-276
+    def __init__(self, config: GPTConfig):
+        super().__init__()
+
+    def forward(self, x, *args):
+        if isinstance(x, EmbedHandle):
+            _check_forward_only(x.tok_weight)
+            return F_mot.embed_mix(x.tokens, _f32(x.tok_weight, "token table"), mode="noop")
+        return x
+
+
+def make_digit_mixin(config: GPTConfig):  # model.py:279-284
+    if config.digit_mixin_method == "cross_attn":
+        raise NotImplementedError("digit_mixin_method='cross_attn' (model.py:239-253) is a later scope row")
+    return {"noop": DigitMixinNoOp, "concat": DigitMixinConcat}[config.digit_mixin_method](config)
+
+
+class DigitFrontEnd(nn.Module):
+    """``wte`` / ``dte`` / ``digit_mixin`` of mathblations' GPT and the first lines of its forward
+    (model.py:304-306, 319-327), nothing else of that model."""
+
+    def __init__(self, config: GPTConfig):
+        super().__init__()
+        self.config = config
+        self.wte = LazyEmbedding(config.vocab_size, config.n_embd_tok, "tokens")
+        self.dte = (LazyEmbedding(14, config.n_embd_digit, "bytes", config.length_factor)
+                    if config.digit_mixin_method != "noop" else nn.Identity())
+        self.digit_mixin = make_digit_mixin(config)
+
+    def forward(self, idx: Tensor, digits: Tensor | None = None) -> Tensor:
+        if self.config.digit_mixin_method != "noop":
+            assert digits is not None, "Digits must be provided"
+        we = self.wte(idx)
+        de = self.dte(digits)
+        return self.digit_mixin(we, de)
+
+
+# ------------------------------------------------------------------------------------------------
+# modded-nanogpt SUM mixin
+# ------------------------------------------------------------------------------------------------
+class SumFrontEnd(nn.Module):
+    """``x = norm(embed_tokens(tok) + concat_k embed_bytes(byte_k))`` (runs/71_*.py:227-230, 312-314) with
+    the per-token byte semantics of train_gpt.py:442 / runs/7_*.py:227-231 (SURVEY section 7, quirk iii).
+    variant "71": plain; "71041": norm each embedding, scale by learned scalars, norm the sum
+    (runs/71041_*.py:311-313); "71081": s_t*norm(E_t) + s_b*concat(norm(E_b)), no outer norm
+    (runs/71081_*.py:302-315).  byte_dim * bytes_per_token must equal model_dim."""
+
+    def __init__(self, token_vocab_size: int, byte_vocab_size: int, model_dim: int, byte_dim: int, bytes_per_token: int = 16,
+                 variant: Literal["71", "71041", "71081"] = "71", ttb=None, pad_byte: int = 456, eot_byte: int = 457):
+        super().__init__()
+        assert byte_dim * bytes_per_token == model_dim
+        self.embed_tokens = nn.Embedding(token_vocab_size, model_dim)
+        self.embed_bytes = nn.Embedding(byte_vocab_size, byte_dim)
+        self.variant, self.bpt, self.pad_byte, self.eot_byte = variant, bytes_per_token, pad_byte, eot_byte
+        self.scalars = nn.Parameter(torch.ones(2)) if variant != "71" else None  # [-2] bytes, [-1] tokens
+        self.register_buffer("ttb", _table_of(ttb).clone() if ttb is not None else None, persistent=False)
+
+    def forward(self, token_inputs: Tensor, byte_inputs: Tensor | None = None) -> Tensor:
+        """token_inputs (T,) or (B,T); byte_inputs (.., T*bpt) per-token-ordered pulled ids, or None to
+        produce them in-kernel from the attached token->byte table."""
+        _check_forward_only(self.embed_tokens.weight, self.embed_bytes.weight, self.scalars)
+        pre = self.variant != "71"
+        kw = dict(norm_tok=pre, norm_byte=pre, norm_out=self.variant != "71081")
+        if pre:
+            kw.update(scale_tok=self.scalars[-1:], scale_byte=self.scalars[-2:-1])
+        if byte_inputs is None:
+            kw.update(ttb=self.ttb, pull="left", pad_byte=self.pad_byte, eot_byte=self.eot_byte)
+        else:
+            kw.update(ids_a=byte_inputs.to(torch.int64).reshape(1 if token_inputs.ndim == 1 else token_inputs.shape[0], -1))
+        return F_mot.embed_mix(token_inputs, _f32(self.embed_tokens.weight, "token table"),
+                               _f32(self.embed_bytes.weight, "byte table"), mode="sum", bpt=self.bpt, **kw)

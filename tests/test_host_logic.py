@@ -1,0 +1,145 @@
+"""CPU tests of the host logic around the kernels: shard format, rank slice + shift against the
+fixtures the reference produced, and the world_size-2 batch-sharded path over gloo."""
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_inputs as gi
+from oracle import oracle as orc
+
+G = gi.GOLDEN_DIR
+REPO = Path(__file__).resolve().parent.parent
+
+
+def test_shard_roundtrip_and_bad_header(tmp_path):
+    from mixture_of_tokenizers_amd import loader
+    toks = np.random.RandomState(0).randint(0, 50257, size=5000)
+    f = tmp_path / "fineweb_train_000001.bin"
+    loader.write_data_shard(f, toks)
+    got = loader._load_data_shard(f)
+    assert got.dtype == torch.uint16 and got.numel() == 5000
+    np.testing.assert_array_equal(got.numpy().astype(np.int64), toks)
+    raw = bytearray(f.read_bytes())
+    assert int.from_bytes(raw[0:4], "little") == 20240520 and int.from_bytes(raw[8:12], "little") == 5000
+    bad = tmp_path / "fineweb_train_000000.bin"
+    raw[0] = 0
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(AssertionError, match="magic"):
+        loader._load_data_shard(bad)
+    # load_data_shard skips the bad shard (train_gpt.py:641-648) and returns int32
+    out = loader.load_data_shard(iter([bad, f]))
+    assert out.dtype == torch.int32 and out.numel() == 5000
+
+
+def test_rank_slice_and_shift_match_reference_fixture():
+    from mixture_of_tokenizers_amd import loader
+    z = np.load(G / "loader.npz")
+    data = torch.from_numpy(z["data"])
+    pos, batch, seq = int(z["pos"]), int(z["batch"]), int(z["seq"])
+    for world in (1, 2, 4):
+        rows = []
+        for rank in range(world):
+            toks = loader.rank_slice(data, pos, batch, seq, rank, world)
+            assert toks.shape == (batch // world, seq + 1)
+            np.testing.assert_array_equal(toks[:, :-1].numpy(), z[f"w{world}r{rank}/toks_in"])
+            np.testing.assert_array_equal(toks[:, 1:].numpy(), z[f"w{world}r{rank}/targets"])
+            rows.append(toks)
+        # the shards tile the global batch exactly: no overlap, no gap
+        assert torch.equal(torch.cat(rows), loader.rank_slice(data, pos, batch, seq, 0, 1))
+    with pytest.raises(AssertionError):
+        loader.rank_slice(data, pos, batch, seq, 0, 3)      # train_gpt.py:795
+
+
+def test_create_data_dispatch_keys():
+    from mixture_of_tokenizers_amd import loader
+    from mixture_of_tokenizers_amd.modules import ByteHyperparameters
+    ok = ByteHyperparameters(byte_mixin_method="concat", pull_in=True, byte_mixout_method="noop", pull_out=False)
+    loader.make_create_data_from_toks(ok, None, None)
+    with pytest.raises(KeyError):   # (True, False, True, False) is not a key of the reference's table (train_gpt.py:766-776)
+        loader.make_create_data_from_toks(
+            ByteHyperparameters(byte_mixin_method="concat", pull_in=False, byte_mixout_method="copy", pull_out=False), None, None)
+
+
+def test_module_names_and_state_dict_keys():
+    """Optimizer groups and checkpoints are built from these names (train_gpt.py:1124-1157)."""
+    from mixture_of_tokenizers_amd import modules as M
+    bp = M.ByteHyperparameters(byte_mixin_method="concat", bytes_per_token=16)
+    dims = M.ModelDims(model_dim=1024, byte_dim=48, token_dim=256)
+
+    class Host(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed = M.FlexibleEmbedding(dims, 50257, bp)
+            self.byte_mixin = M.ByteMixin(dims, 1024, bp)
+
+    h = Host()
+    assert list(h.state_dict()) == ["embed.embed_tokens.weight", "embed.embed_bytes.weight", "byte_mixin.mixin.mixin.weight"]
+    assert h.byte_mixin.mixin.mixin.weight.shape == (1024, 256 + 16 * 48)
+    assert isinstance(h.embed.embed_tokens, torch.nn.Embedding) and isinstance(h.byte_mixin.mixin.attention, torch.nn.Identity)
+    assert [n for n, _ in h.named_parameters() if "embed" in n] == ["embed.embed_tokens.weight", "embed.embed_bytes.weight"]
+    w = h.byte_mixin.mixin.mixin.weight
+    bound = (3 ** 0.5) * 0.5 * w.shape[1] ** -0.5
+    assert float(w.detach().abs().max()) <= bound                      # CastedLinear init, train_gpt.py:179-183
+    noop = M.ByteHyperparameters(byte_mixin_method="noop")
+    e = M.FlexibleEmbedding(dims, 100, noop)
+    assert e.embed_tokens.weight.shape == (100, 1024) and isinstance(e.embed_bytes, torch.nn.Identity)   # train_gpt.py:330-331
+    with pytest.raises(RuntimeError, match="Invalid byte mixin method"):
+        M.ByteMixin(dims, 8, M.ByteHyperparameters(byte_mixin_method="bogus"))
+    cfg = M.GPTConfig(vocab_size=1003, n_embd_tok=256, n_embd_digit=256, length_factor=3, digit_mixin_method="concat")
+    fe = M.DigitFrontEnd(cfg)
+    assert list(fe.state_dict()) == ["wte.weight", "dte.weight", "digit_mixin.fc.weight", "digit_mixin.fc.bias"]
+    assert fe.digit_mixin.fc.weight.shape == (256, 1024)
+    with pytest.raises(AssertionError, match="Digits must be provided"):
+        fe(torch.zeros(1, 4, dtype=torch.long), None)
+
+
+# ---------------------------------------------------------------------------------------------
+# world_size 2 over gloo: every rank runs the front-end's integer path (the oracle stands in for the
+# GPU kernels on this CPU-only host) on its shard; the only collective is the counter all-reduce.
+# ---------------------------------------------------------------------------------------------
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mixture_of_tokenizers_amd import loader
+    z = np.load(G / "loader.npz")
+    data = torch.from_numpy(z["data"])
+    pos, batch, seq = int(z["pos"]), int(z["batch"]), int(z["seq"])
+    toks = loader.rank_slice(data, pos, batch, seq, rank, world)
+    bpt = 16
+    tab = gi.synth_ttb(3001, 512, bpt, "left").astype(np.float32)
+    padded = orc.tokens_to_bytes(toks.numpy(), tab)
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    st = orc.byte_stats(padded, pulled, gi.PAD)
+    counters = torch.tensor([toks.numel(), int(st[0]), int(st[1]), int(st[2])], dtype=torch.int64)
+    dist.all_reduce(counters, op=dist.ReduceOp.SUM)          # what bench.py does over RCCL
+    gathered = [torch.empty_like(torch.from_numpy(pulled)) for _ in range(world)]
+    dist.all_gather(gathered, torch.from_numpy(pulled))
+    if rank == 0:
+        torch.save(dict(counters=counters, pulled=torch.cat(gathered)), tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    out = tmp_path / "w2.pt"
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_worker, args=(2, port, str(out)), nprocs=2, join=True)
+    res = torch.load(out)
+    from mixture_of_tokenizers_amd import loader
+    z = np.load(G / "loader.npz")
+    data = torch.from_numpy(z["data"])
+    pos, batch, seq = int(z["pos"]), int(z["batch"]), int(z["seq"])
+    toks = loader.rank_slice(data, pos, batch, seq, 0, 1).numpy()
+    tab = gi.synth_ttb(3001, 512, 16, "left").astype(np.float32)
+    padded = orc.tokens_to_bytes(toks, tab)
+    pulled = orc.pull_from_left(padded, 16, gi.PAD, gi.EOT)
+    np.testing.assert_array_equal(res["pulled"].numpy(), pulled)         # sharded == unsharded, bit for bit
+    st = orc.byte_stats(padded, pulled, gi.PAD)
+    assert res["counters"].tolist() == [toks.size, int(st[0]), int(st[1]), int(st[2])]
