@@ -59,7 +59,8 @@ def test_scaled_pretrain_modules(M, case, fused):
         assert x.shape == (B, T, Dm) and x.dtype == torch.float32
         assert_gemm_close(host(x), z[f"{name}/{mode}/f32/x"], z[f"{name}/{mode}/f64/x"])
         if not fused and name == "small":
-            te, be = net.embed(toks, padded, pulled)
+            with torch.no_grad():
+                te, be = net.embed(toks, padded, pulled)
             assert_close(host(te), z[f"{name}/{mode}/f32/tok_embs"])
             assert_close(host(be), z[f"{name}/{mode}/f32/byte_embs"])
     bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="noop")
@@ -137,7 +138,9 @@ def test_loader_create_data_matches_reference_fixture():
     z = np.load(G / "loader.npz")
     bpt, vocab = 16, 512
     tab = dev(gi.synth_ttb(3001, vocab, bpt, "left"))
-    bp = ByteHyperparameters(bytes_per_token=bpt, byte_mixin_method="concat", pull_in=True, byte_mixout_method="noop")
+    # main() forces pull_out=False when the mixout is noop (train_gpt.py:1013-1014); any other combination is
+    # a KeyError in the reference's dispatch table too (train_gpt.py:766-783)
+    bp = ByteHyperparameters(bytes_per_token=bpt, byte_mixin_method="concat", pull_in=True, byte_mixout_method="noop", pull_out=False)
     create = loader.make_create_data_from_toks(bp, tab, tab)          # _create_data_from_toks_TT_FF
     data = torch.from_numpy(z["data"])
     pos, batch, seq = int(z["pos"]), int(z["batch"]), int(z["seq"])
