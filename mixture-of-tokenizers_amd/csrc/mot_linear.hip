@@ -18,6 +18,8 @@
 // K is walked in steps of 16 with double-buffered LDS: the next step's W chunk (from the k-major
 // transposed copy the prologue kernel writes to the workspace) and A chunk are loaded to registers
 // before the current step's MFMAs and written to the other buffer after them; one barrier per step.
+#include <stdlib.h>
+
 #include "mot_mix.hpp"
 
 namespace mot {
@@ -66,8 +68,10 @@ __global__ __launch_bounds__(kThreads) void transpose_pad_kernel(const float *__
 }
 
 // MT x NT accumulator tiles of 32x32 per wave: the workgroup tile is kTM = 32*MT tokens x 128*NT columns.
-template <int MT, int NT, int kBK>
-__global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const LinArgs P) {
+// ABL: timing-only ablation bits (results are wrong when set): 1 = chain straight into the running
+// accumulator (no blocked-sum adds), 2 = no per-step global loads, 4 = no per-step LDS stores, 8 = no barrier.
+template <int MT, int NT, int kBK, int OCC, int ABL = 0>
+__global__ __launch_bounds__(kThreads, OCC) void embed_mix_linear_kernel(const LinArgs P) {
     constexpr int kTM = 32 * MT;
     constexpr int WP = kBK * NT / 8;  // float4 of the W chunk per thread
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const Lin
     store_stage(0);
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
-        load_stage(min(s + 1, nsteps - 1));  // the last step re-loads itself: keeps the body branch-free
+        if (!(ABL & 2)) load_stage(min(s + 1, nsteps - 1));  // the last step re-loads itself: keeps the body branch-free
         const float *Ab = S.A0 + (s & 1) * (kBK * kTM), *Wb = S.W0 + (s & 1) * (kBK * P.DmPad);
         // v_mfma_f32_32x32x2_f32: lane l holds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31].
         // Blocked summation: the kBK products of this step are chained in a fresh accumulator and
@@ -218,31 +222,63 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_kernel(const Lin
         for (int kp = 0; kp < kBK / 2; ++kp)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) af[mt][kp] = Ab[(2 * kp + h) * kTM + mt * 32 + li];
-        // Software pipeline over the 2*NT accumulator tiles: tile j's kBK/2 chained MFMAs run while
-        // the VALU adds tile j-1's finished partial sum into the running accumulator.
-        f32x16 prev = zero16;
+        // Software pipeline over the MT*NT accumulator tiles of this step.  While tile j's kBK/2 chained
+        // MFMAs issue (64 cycles each on the SIMD's matrix pipe), the other pipes work in their shadow:
+        //   - the VALU adds tile j-1's finished partial sum into the running accumulator,
+        //   - LDS reads fetch the B fragments of the NEXT column block (so no MFMA waits on a read that
+        //     was issued one MFMA earlier: ds_read latency is about one MFMA long),
+        // and the sched_group_barrier sequence pins that interleave per MFMA.
+        float bf[2][kBK / 2];
+#pragma unroll
+        for (int kp = 0; kp < kBK / 2; ++kp) bf[0][kp] = Wb[(2 * kp + h) * P.DmPad + n0 + li];
+        f32x16 prev0 = zero16, prev1 = zero16;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            float bf[kBK / 2];
+            if (nt + 1 < NT) {
 #pragma unroll
-            for (int kp = 0; kp < kBK / 2; ++kp) bf[kp] = Wb[(2 * kp + h) * P.DmPad + n0 + nt * 32 + li];
+                for (int kp = 0; kp < kBK / 2; ++kp) bf[(nt + 1) & 1][kp] = Wb[(2 * kp + h) * P.DmPad + n0 + (nt + 1) * 32 + li];
+            }
+            if (ABL & 1) {   // timing only: straight chains into the running accumulators, no adds
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                f32x16 part = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][0], bf[0], zero16, 0, 0, 0);
+                for (int kp = 0; kp < kBK / 2; ++kp)
 #pragma unroll
-                for (int kp = 1; kp < kBK / 2; ++kp) part = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][kp], bf[kp], part, 0, 0, 0);
-                if (nt > 0 || mt > 0) acc[(mt + MT - 1) % MT][mt == 0 ? nt - 1 : nt] += prev;  // the previous tile
-                prev = part;
+                    for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mt][kp], bf[nt & 1][kp], acc[mt][nt], 0, 0, 0);
+            } else if (MT == 2) {
+                // the two row tiles of this column block share the B fragments; their chains are
+                // interleaved so that consecutive MFMAs never depend on each other
+                f32x16 p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][0], bf[nt & 1][0], zero16, 0, 0, 0);
+                f32x16 p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[MT - 1][0], bf[nt & 1][0], zero16, 0, 0, 0);
 #pragma unroll
-                for (int kp = 0; kp < kBK / 2; ++kp) {  // per MFMA: a few of the previous tile's adds
+                for (int kp = 1; kp < kBK / 2; ++kp) {
+                    p0 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][kp], bf[nt & 1][kp], p0, 0, 0, 0);
+                    p1 = __builtin_amdgcn_mfma_f32_32x32x2f32(af[MT - 1][kp], bf[nt & 1][kp], p1, 0, 0, 0);
+                }
+                if (nt > 0) { acc[0][nt - 1] += prev0; acc[MT - 1][nt - 1] += prev1; }
+                prev0 = p0; prev1 = p1;
+#pragma unroll
+                for (int kp = 0; kp < kBK; ++kp) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+                    if ((kp & 1) == 0 && nt + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one B-fragment read
+                    __builtin_amdgcn_sched_group_barrier(0x002, 48 / (kBK / 2), 0);        // a slice of the adds
+                }
+            } else {
+                f32x16 part = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][0], bf[nt & 1][0], zero16, 0, 0, 0);
+#pragma unroll
+                for (int kp = 1; kp < kBK / 2; ++kp) part = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][kp], bf[nt & 1][kp], part, 0, 0, 0);
+                if (nt > 0) acc[0][nt - 1] += prev0;
+                prev0 = part;
+#pragma unroll
+                for (int kp = 0; kp < kBK / 2; ++kp) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (nt + 1 < NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x002, 48 / (kBK / 2), 0);
                 }
             }
         }
-        acc[MT - 1][NT - 1] += prev;
-        store_stage((s + 1) & 1);
-        __syncthreads();
+        acc[0][NT - 1] += prev0;
+        if (MT == 2) acc[MT - 1][NT - 1] += prev1;
+        if (!(ABL & 4)) store_stage((s + 1) & 1);
+        if (!(ABL & 8)) __syncthreads();
     }
 
     // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -314,7 +350,7 @@ size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d) {
     return (Kpad * DmPad + (size_t)d.byte_rows) * sizeof(float);
 }
 
-template <int MT, int NT, int BK>
+template <int MT, int NT, int BK, int OCC = 1, int ABL = 0>
 static int launch_lin(LinArgs &P, const MotEmbedMixDesc &d, hipStream_t stream) {
     constexpr int TM = 32 * MT;
     P.M.tile_tokens = TM;
@@ -327,11 +363,11 @@ static int launch_lin(LinArgs &P, const MotEmbedMixDesc &d, hipStream_t stream) 
         return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: needs %zu B of LDS (model_dim %d, bpt %d) > 160 KiB", lds, P.Dm, P.M.bpt);
     static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent; a race sets it twice at worst
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_kernel<MT, NT, BK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_kernel<MT, NT, BK, OCC, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_linear_kernel): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_mix_linear_kernel<MT, NT, BK>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, P);
+    hipLaunchKernelGGL((embed_mix_linear_kernel<MT, NT, BK, OCC, ABL>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, P);
     return check_launch("embed_mix_linear_kernel");
 }
 
@@ -371,7 +407,18 @@ int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) {
         case 2: return launch_lin<2, 2, 16>(P, d, stream);
         case 3: return launch_lin<2, 3, 16>(P, d, stream);
         case 4: return launch_lin<2, 4, 16>(P, d, stream);
-        case 6: return launch_lin<2, 6, 16>(P, d, stream);
+        case 6: {
+#ifdef MOT_DEV_ABLATION  // timing-only variants (wrong results), see the ABL template parameter
+            const char *abl = getenv("MOT_LIN_ABL");
+            if (abl) switch (atoi(abl)) {
+                case 1: return launch_lin<2, 6, 16, 1, 1>(P, d, stream);
+                case 6: return launch_lin<2, 6, 16, 1, 6>(P, d, stream);
+                case 14: return launch_lin<2, 6, 16, 1, 14>(P, d, stream);
+                case 15: return launch_lin<2, 6, 16, 1, 15>(P, d, stream);
+            }
+#endif
+            return launch_lin<2, 6, 16>(P, d, stream);
+        }
         default: return launch_lin<1, 8, 16>(P, d, stream);
     }
 }
