@@ -386,6 +386,96 @@ def gen_mathblations(mmodel, mdata):
     print("mathblations:", len(out), "arrays", "x", out["concat/f32/x"].shape)
 
 
+# ------------------------------------------------------------------ gradients (autograd of the reference)
+def gen_grads(dc, tg, r71, mmodel):
+    """dL/dparams for L = sum(x * g), g seeded: what loss.backward() (train_gpt.py:1319, main.py:304)
+    leaves in .grad for the parameters of the path.  Small shapes; fp32 and float64."""
+    out = {}
+    norm, mixin_bytes = r71["norm"], r71["mixin_bytes"]
+    # SUM family (runs/71, 71041, 71081)
+    name, Vt, D, Db, bpt, T, seed = SUM_CASES[0]
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+    pulled = dc.pull_from_left(dc.tokens_to_bytes(torch.from_numpy(toks), ttb_embedding(tab)), bpt, gi.PAD, gi.EOT)
+    byte_inputs = pulled.view(T, bpt).t().contiguous()
+    g = np.random.RandomState(seed + 77).standard_normal((1, T, D))
+    out["sum/g"] = g
+    for dt_name, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+        for variant in ("r71", "r71041", "r71081"):
+            et = torch.from_numpy(gi.normal_table(seed + 1, Vt, D)).to(tdt).requires_grad_()
+            eb = torch.from_numpy(gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db)).to(tdt).requires_grad_()
+            sc = torch.tensor([0.75, 1.25], dtype=tdt, requires_grad=True)       # [-2] bytes, [-1] tokens
+            tok1d = torch.from_numpy(toks[0]).long()
+            if variant == "r71":
+                x = mixin_bytes(et[tok1d][None], eb[byte_inputs].squeeze())
+            elif variant == "r71041":
+                x = mixin_bytes(norm(et[tok1d][None]) * sc[-1], norm(eb[byte_inputs].squeeze()) * sc[-2])
+            else:
+                x0b = norm(eb[byte_inputs].squeeze())
+                x = norm(et[tok1d][None]) * sc[-1] + torch.cat([b for b in x0b], dim=-1)[None] * sc[-2]
+            (x * torch.from_numpy(g).to(tdt)).sum().backward()
+            out[f"sum/{variant}/{dt_name}/d_tok"] = t2n(et.grad)
+            out[f"sum/{variant}/{dt_name}/d_byte"] = t2n(eb.grad)
+            if variant != "r71":
+                out[f"sum/{variant}/{dt_name}/d_scalars"] = t2n(sc.grad)
+    # scaled-pre-train concat (FlexibleEmbedding + ByteMixinConcat), three byte modes + noop
+    name, Vt, Dt, Db, Dm, bpt, B, T, seed = SCALED_CASES[0]
+    tab, toks = scaled_inputs(dc, name, Vt, Dt, Db, Dm, bpt, B, T, seed)
+    padded = dc.tokens_to_bytes(torch.from_numpy(toks), ttb_embedding(tab))
+    pulled = dc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    g = np.random.RandomState(seed + 77).standard_normal((B, T, Dm))
+    out["scaled/g"] = g
+    for dt_name, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+        for mode, bp_kw in (("padded", dict(pull_in=False)), ("pulled", dict(pull_in=True)),
+                            ("padded_and_pulled", dict(pull_in=True, add_padded_and_pulled=True))):
+            bp = tg["ByteHyperparameters"](bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", **bp_kw)
+            dims = tg["ModelDims"](model_dim=Dm, byte_dim=Db, token_dim=Dt)
+            emb, mix = tg["FlexibleEmbedding"](dims, Vt, bp), tg["ByteMixin"](dims, T, bp)
+            emb.embed_tokens.weight.data = torch.from_numpy(gi.normal_table(seed + 1, Vt, Dt)).to(tdt)
+            emb.embed_bytes.weight.data = torch.from_numpy(gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db)).to(tdt)
+            mix.mixin.mixin.weight.data = torch.from_numpy(gi.casted_linear_weight(seed + 3, Dm, Dt + bpt * Db)).to(tdt)
+            xt, xb = emb(tokens=torch.from_numpy(toks), byte_tensor=padded, byte_tensor_pulled=pulled)
+            (mix(xt, xb) * torch.from_numpy(g).to(tdt)).sum().backward()
+            out[f"scaled/{mode}/{dt_name}/d_tok"] = t2n(emb.embed_tokens.weight.grad)
+            out[f"scaled/{mode}/{dt_name}/d_byte"] = t2n(emb.embed_bytes.weight.grad)
+            out[f"scaled/{mode}/{dt_name}/d_W"] = t2n(mix.mixin.mixin.weight.grad)
+        bp = tg["ByteHyperparameters"](bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="noop")
+        emb = tg["FlexibleEmbedding"](tg["ModelDims"](model_dim=Dt, byte_dim=Db, token_dim=Dt), Vt, bp)
+        emb.embed_tokens.weight.data = torch.from_numpy(gi.normal_table(seed + 1, Vt, Dt)).to(tdt)
+        xt, _ = emb(tokens=torch.from_numpy(toks), byte_tensor=None, byte_tensor_pulled=None)
+        gn = np.random.RandomState(seed + 78).standard_normal((B, T, Dt))
+        out["scaled/g_noop"] = gn
+        (xt * torch.from_numpy(gn).to(tdt)).sum().backward()
+        out[f"scaled/noop/{dt_name}/d_tok"] = t2n(emb.embed_tokens.weight.grad)
+    # mathblations DigitMixinConcat (bias, digits first), small dims, tied wte/lm_head
+    D = 32
+    random.seed(1)
+    import data as mdata  # type: ignore
+    gen = mdata.GenerateEquations()
+    xs, xd = zip(*[(lambda r: (r[0], r[1]))(gen()) for _ in range(3)])
+    x_tokens, x_digits = torch.stack(xs), torch.stack(xd)
+    out["math/x_tokens"], out["math/x_digit_tokens"] = t2n(x_tokens), t2n(x_digits)
+    g = np.random.RandomState(991).standard_normal((3, 32, D))
+    out["math/g"] = g
+    cfg = mmodel.GPTConfig(vocab_size=gen.vocab_size, n_layer=1, n_head=2, n_embd_tok=D, n_embd_digit=D, T=32,
+                           length_factor=3, digit_mixin_method="concat")
+    for dt_name, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+        net = mmodel.GPT(cfg).to(tdt)
+        net.lm_head.weight.data = torch.from_numpy(gi.normal_table(611, gen.vocab_size, D)).to(tdt)
+        net.dte.weight.data = torch.from_numpy(gi.normal_table(612, 14, D)).to(tdt)
+        Wf, bf = gi.linear_weight_bias(613, D, 4 * D)
+        net.digit_mixin.fc.weight.data = torch.from_numpy(Wf).to(tdt)
+        net.digit_mixin.fc.bias.data = torch.from_numpy(bf).to(tdt)
+        x = net.digit_mixin(net.wte(x_tokens), net.dte(x_digits))
+        (x * torch.from_numpy(g).to(tdt)).sum().backward()
+        out[f"math/{dt_name}/d_tok"] = t2n(net.wte.weight.grad)
+        out[f"math/{dt_name}/d_byte"] = t2n(net.dte.weight.grad)
+        out[f"math/{dt_name}/d_W"] = t2n(net.digit_mixin.fc.weight.grad)
+        out[f"math/{dt_name}/d_bias"] = t2n(net.digit_mixin.fc.bias.grad)
+    np.savez_compressed(OUT / "grads.npz", **out)
+    print("grads:", len(out), "arrays")
+
+
 def main():
     dc = load_data_creation()
     gen_ttb_fixture()
@@ -394,7 +484,9 @@ def main():
     gen_loader(dc)
     gen_scaled(dc, load_train_gpt_defs())
     gen_sum(dc, load_run71_defs())
-    gen_mathblations(*load_mathblations())
+    mm = load_mathblations()
+    gen_mathblations(*mm)
+    gen_grads(dc, load_train_gpt_defs(), load_run71_defs(), mm[0])
     meta = dict(torch=torch.__version__, numpy=np.__version__, python=sys.version.split()[0],
                 threads=torch.get_num_threads(), reference="snimu/mixture-of-tokenizers @ 2025-08-24",
                 generator="oracle/gen_golden.py")

@@ -194,3 +194,42 @@ def embed_mix(tokens, ids_a, ids_b, tok_table, byte_table, *, mode, bpt, weight=
     if return_seam:
         return out, te.reshape(*tok.shape, Dt), (None if be is None else be.reshape(*tok.shape[:-1], -1, Db))
     return out
+
+
+def embed_mix_bwd(tokens, ids_a, ids_b, tok_table, byte_table, grad_out, *, mode, bpt, weight=None, bias=None,
+                  bytes_first=False, norm_tok=False, norm_byte=False, norm_out=False,
+                  scale_tok=1.0, scale_byte=1.0, dtype=np.float32):
+    """Gradients of embed_mix w.r.t. (tok_table, byte_table, weight, bias, [scale_tok, scale_byte]) for
+    upstream gradient `grad_out` (tokens.shape + (Dm,)); float64 arrays (see mot_oracle_float.inc)."""
+    real = C.c_float if dtype == np.float32 else C.c_double
+    fn = lib().oracle_embed_mix_bwd_f32 if dtype == np.float32 else lib().oracle_embed_mix_bwd_f64
+    tok = _c(tokens, np.int32)
+    n = tok.size
+    tt = _c(tok_table, dtype)
+    Dt = tt.shape[1]
+    m = _MODES[mode]
+    if m == MODE_NOOP:
+        bt, ia, ib, bpt_ = np.zeros((1, 1), dtype=dtype), None, None, 0
+    else:
+        bt = _c(byte_table, dtype)
+        ia = _c(ids_a, np.int64).reshape(-1)
+        ib = None if ids_b is None else _c(ids_b, np.int64).reshape(-1)
+        bpt_ = bpt
+    Db = bt.shape[1]
+    w = _c(weight, dtype) if m == MODE_CONCAT_LINEAR else None
+    Dm = w.shape[0] if w is not None else Dt
+    bs = None if bias is None else _c(bias, dtype)
+    g = _c(grad_out, dtype).reshape(n, Dm)
+    d_tok = np.zeros(tt.shape, dtype=np.float64)
+    d_byte = np.zeros(bt.shape, dtype=np.float64)
+    d_w = np.zeros(w.shape, dtype=np.float64) if w is not None else None
+    d_b = np.zeros(Dm, dtype=np.float64) if bs is not None else None
+    d_s = np.zeros(2, dtype=np.float64)
+    _check(fn(_p(tok, C.c_int32), C.c_int64(n), _p(ia, C.c_int64), _p(ib, C.c_int64), C.c_int(bpt_),
+              _p(tt, real), C.c_int64(tt.shape[0]), C.c_int(Dt), _p(bt, real), C.c_int64(bt.shape[0]), C.c_int(Db),
+              C.c_int(m), C.c_int(int(bytes_first)), _p(w, real), _p(bs, real), C.c_int(Dm),
+              C.c_int(int(norm_tok)), C.c_int(int(norm_byte)), C.c_int(int(norm_out)),
+              C.c_double(scale_tok), C.c_double(scale_byte), _p(g, real),
+              _p(d_tok, C.c_double), _p(d_byte, C.c_double), _p(d_w, C.c_double), _p(d_b, C.c_double),
+              _p(d_s, C.c_double)), "embed_mix_bwd")
+    return dict(tok_table=d_tok, byte_table=None if m == MODE_NOOP else d_byte, weight=d_w, bias=d_b, scales=d_s)

@@ -189,3 +189,68 @@ def test_sum_modes(case):
         x32 = orc.embed_mix(toks, pulled, None, f32(Et), f32(Eb), mode="sum", bpt=bpt, dtype=np.float32, **kw)
         # headline bar: fp32 mixed embeddings within 1e-6 of the reference CPU path
         np.testing.assert_allclose(x32, z[f"{name}/{v}/f32"], rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# backward: the oracle's analytic gradients vs what autograd left in .grad for the reference modules
+# (tests/golden/grads.npz, L = sum(x * g)).  float64 oracle vs float64 reference: 1e-10 relative to
+# the largest gradient entry; fp32 oracle (double accumulators) vs the reference's fp32 grads: 2e-5.
+# ------------------------------------------------------------------------------------------------
+def _rel(got, ref):
+    return np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+def grad_cases():
+    z = np.load(G / "grads.npz")
+    name, Vt, D, Db, bpt, T, seed = SUMC[0]
+    toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, ttb_f32(tab)), bpt, gi.PAD, gi.EOT)
+    Et, Eb = gi.normal_table(seed + 1, Vt, D), gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db)
+    sk = dict(scale_tok=1.25, scale_byte=0.75)
+    for v, kw in (("r71", dict(norm_out=True)), ("r71041", dict(norm_tok=True, norm_byte=True, norm_out=True, **sk)),
+                  ("r71081", dict(norm_tok=True, norm_byte=True, **sk))):
+        yield f"sum/{v}", dict(tokens=toks, ids_a=pulled, ids_b=None, tok_table=Et, byte_table=Eb, grad_out=z["sum/g"],
+                               mode="sum", bpt=bpt, **kw), z
+    name, Vt, Dt, Db, Dm, bpt, B, T, seed = SCALED[0]
+    toks = gi.edge_tokens(seed, B, T, Vt, eot_p=0.08)
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    padded = orc.tokens_to_bytes(toks, ttb_f32(tab))
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    Et, Eb = gi.normal_table(seed + 1, Vt, Dt), gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db)
+    W = gi.casted_linear_weight(seed + 3, Dm, Dt + bpt * Db)
+    for mode, (ia, ib) in dict(padded=(padded, None), pulled=(pulled, None), padded_and_pulled=(padded, pulled)).items():
+        yield f"scaled/{mode}", dict(tokens=toks, ids_a=ia, ids_b=ib, tok_table=Et, byte_table=Eb, grad_out=z["scaled/g"],
+                                     mode="concat_linear", bpt=bpt, weight=W, norm_tok=True, norm_byte=True, norm_out=True), z
+    yield "scaled/noop", dict(tokens=toks, ids_a=None, ids_b=None, tok_table=Et, byte_table=None, grad_out=z["scaled/g_noop"],
+                              mode="noop", bpt=bpt, norm_tok=True), z
+    D = 32
+    Wf, bf = gi.linear_weight_bias(613, D, 4 * D)
+    yield "math", dict(tokens=z["math/x_tokens"], ids_a=z["math/x_digit_tokens"], ids_b=None,
+                       tok_table=gi.normal_table(611, 1003, D), byte_table=gi.normal_table(612, 14, D), grad_out=z["math/g"],
+                       mode="concat_linear", bpt=3, weight=Wf, bias=bf, bytes_first=True), z
+
+
+GRAD_KEYS = (("tok_table", "d_tok"), ("byte_table", "d_byte"), ("weight", "d_W"), ("bias", "d_bias"))
+
+
+@pytest.mark.parametrize("case", list(grad_cases()), ids=lambda c: c[0])
+def test_backward_oracle_vs_reference_autograd(case):
+    name, kw, z = case
+    kw = dict(kw)
+    f64 = orc.embed_mix_bwd(dtype=np.float64, **kw)
+    for k in ("tok_table", "byte_table", "weight", "bias", "grad_out"):
+        if kw.get(k) is not None:
+            kw[k] = f32(kw[k])
+    g32 = orc.embed_mix_bwd(dtype=np.float32, **kw)
+    base = name if name.startswith("math") else name
+    for ours, theirs in GRAD_KEYS:
+        key64 = f"{base}/f64/{theirs}"
+        if key64 not in z:
+            continue
+        assert _rel(f64[ours], z[key64]) < 1e-10, (name, ours)
+        assert _rel(g32[ours], z[key64]) < 2e-5, (name, ours)
+        assert _rel(g32[ours], z[f"{base}/f32/{theirs}"]) < 2e-5, (name, ours)
+    if f"{base}/f64/d_scalars" in z:      # [-2] bytes, [-1] tokens (runs/71041_*.py:311-312)
+        ref = z[f"{base}/f64/d_scalars"]
+        assert abs(f64["scales"][0] - ref[1]) < 1e-9 * abs(ref).max() and abs(f64["scales"][1] - ref[0]) < 1e-9 * abs(ref).max()
