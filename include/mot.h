@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 1
+#define MOT_ABI_VERSION 2
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -187,6 +187,32 @@ typedef struct MotEmbedMixDesc {
     void *workspace; /* >= mot_embed_mix_workspace_bytes(desc); may be NULL when that is 0 */
     size_t workspace_bytes;
 } MotEmbedMixDesc;
+
+/*
+ * Backward of mot_embed_mix_fwd: replaces what autograd does for the modules above when the
+ * training loop calls loss.backward() (scaled-pre-train/train_gpt.py:1319; mathblations/main.py:304).
+ * `fwd` is the forward's descriptor with id_source == MOT_IDS_GIVEN (pass the byte ids the forward
+ * returned through out_ids_*); `out`, `out_ids_*`, `counters` are ignored.  Gradients are ACCUMULATED
+ * (+=) into the given buffers, so a parameter's .grad can be passed directly; NULL = not wanted.
+ * Built this round: MOT_MIX_SUM and MOT_MIX_NOOP (others return MOT_EUNSUPPORTED).
+ * Sums use float atomics: results are order-dependent in the last bits, like the reference's own
+ * GPU embedding backward.
+ */
+typedef struct MotEmbedMixGrads {
+    uint32_t struct_size;  /* sizeof(MotEmbedMixGrads) */
+    uint32_t reserved;
+    const void *grad_out;  /* [B, T, model_dim] upstream gradient dL/dx */
+    void *d_tok_table;     /* [tok_rows, tok_dim]   */
+    void *d_byte_table;    /* [byte_rows, byte_dim] */
+    void *d_weight;        /* [model_dim, K]   (CONCAT_LINEAR, not built yet) */
+    void *d_bias;          /* [model_dim]      (CONCAT_LINEAR, not built yet) */
+    float *d_scale_tok;    /* scalar */
+    float *d_scale_byte;   /* scalar */
+} MotEmbedMixGrads;
+
+size_t mot_embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc *fwd /* host */);
+int mot_embed_mix_bwd(const MotEmbedMixDesc *fwd /* host */, const MotEmbedMixGrads *grads /* host */,
+                      mot_stream_t stream);
 
 size_t mot_embed_mix_desc_size(void); /* sizeof(MotEmbedMixDesc) in this build, for bindings */
 size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc /* host */);

@@ -23,12 +23,12 @@ MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32 = 0
 MAX_BPT = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EXPORTS = (
     "mot_version", "mot_last_error", "mot_build_info", "mot_tokens_to_bytes", "mot_pull_bytes",
     "mot_create_batch", "mot_gather_rows", "mot_embed_mix_desc_size", "mot_embed_mix_workspace_bytes",
-    "mot_embed_mix_fwd",
+    "mot_embed_mix_fwd", "mot_embed_mix_bwd_workspace_bytes", "mot_embed_mix_bwd",
 )
 
 
@@ -52,6 +52,15 @@ class MotEmbedMixDesc(C.Structure):
     ]
 
 
+class MotEmbedMixGrads(C.Structure):
+    """Mirror of struct MotEmbedMixGrads (include/mot.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("grad_out", C.c_void_p),
+        ("d_tok_table", C.c_void_p), ("d_byte_table", C.c_void_p), ("d_weight", C.c_void_p), ("d_bias", C.c_void_p),
+        ("d_scale_tok", C.c_void_p), ("d_scale_byte", C.c_void_p),
+    ]
+
+
 def _load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise ImportError(
@@ -70,7 +79,11 @@ def _load() -> C.CDLL:
     lib.mot_embed_mix_workspace_bytes.restype = C.c_size_t
     lib.mot_embed_mix_workspace_bytes.argtypes = [C.POINTER(MotEmbedMixDesc)]
     lib.mot_embed_mix_fwd.argtypes = [C.POINTER(MotEmbedMixDesc), vp]
-    for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_gather_rows", "mot_embed_mix_fwd"):
+    lib.mot_embed_mix_bwd_workspace_bytes.restype = C.c_size_t
+    lib.mot_embed_mix_bwd_workspace_bytes.argtypes = [C.POINTER(MotEmbedMixDesc)]
+    lib.mot_embed_mix_bwd.argtypes = [C.POINTER(MotEmbedMixDesc), C.POINTER(MotEmbedMixGrads), vp]
+    for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_gather_rows", "mot_embed_mix_fwd",
+                 "mot_embed_mix_bwd"):
         getattr(lib, name).restype = C.c_int
     if lib.mot_version() != ABI_VERSION:
         raise ImportError(f"libmot_hip.so ABI {lib.mot_version()} != binding ABI {ABI_VERSION}")

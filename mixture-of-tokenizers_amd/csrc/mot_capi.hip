@@ -156,6 +156,27 @@ size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc) {
     return embed_mix_workspace_bytes(*desc);
 }
 
+size_t mot_embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc *desc) {
+    if (!desc || desc->struct_size != sizeof(MotEmbedMixDesc)) return 0;
+    return embed_mix_bwd_workspace_bytes(*desc);
+}
+
+int mot_embed_mix_bwd(const MotEmbedMixDesc *desc, const MotEmbedMixGrads *grads, mot_stream_t stream) {
+    if (!grads || grads->struct_size != sizeof(MotEmbedMixGrads))
+        return set_error(MOT_EINVAL, "embed_mix_bwd: grads struct missing or struct_size mismatch");
+    MotEmbedMixDesc d;
+    if (!desc) return set_error(MOT_EINVAL, "embed_mix_bwd: null descriptor");
+    d = *desc;
+    if (!d.out) d.out = (void *)grads->grad_out;  // the forward validator wants a non-null `out`; it is not touched
+    int rc = validate_embed_mix(&d);
+    if (rc) return rc;
+    if (!grads->grad_out) return set_error(MOT_EINVAL, "embed_mix_bwd: grad_out missing");
+    if (!grads->d_tok_table) return set_error(MOT_EINVAL, "embed_mix_bwd: d_tok_table missing");
+    if (d.mode == MOT_MIX_SUM && !grads->d_byte_table) return set_error(MOT_EINVAL, "embed_mix_bwd: d_byte_table missing");
+    if (d.n_rows == 0 || d.tokens_per_row == 0) return MOT_OK;
+    return launch_embed_mix_bwd(d, *grads, (hipStream_t)stream);
+}
+
 int mot_embed_mix_fwd(const MotEmbedMixDesc *desc, mot_stream_t stream) {
     int rc = validate_embed_mix(desc);
     if (rc) return rc;

@@ -29,5 +29,7 @@ size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream);         // SUM / MEAN / NOOP
 int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream);  // CONCAT_LINEAR
 size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d);
+size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d);
+int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hipStream_t stream);
 
 }  // namespace mot

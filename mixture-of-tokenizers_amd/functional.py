@@ -127,7 +127,7 @@ def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor | None:
 
 
 @torch.compiler.disable
-def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor | None = None, *,
+def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor | None = None, *,
               mode: str, bpt: int = 0,
               ttb: torch.Tensor | None = None, pull: str | None = None, add_padded: bool = False,
               pad_byte: int = 456, eot_byte: int = 457,
@@ -229,3 +229,126 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
     if return_ids:
         return MixResult(out, ids_padded, ids_pulled)
     return out
+
+
+_BWD_MODES = ("sum", "noop")
+
+
+class _EmbedMixFn(torch.autograd.Function):
+    """Autograd node of the fused front-end: forward = one mot_embed_mix_fwd launch, backward = one
+    mot_embed_mix_bwd launch (dense gradients, like nn.Embedding(sparse=False) in the reference)."""
+
+    @staticmethod
+    def forward(ctx, tok_table, byte_table, scale_tok, scale_byte, tokens, kw):
+        kw = dict(kw)
+        mode = kw["mode"]
+        want_ids = kw.get("ttb") is not None and mode != "noop"
+        user_return_ids = kw.pop("return_ids", False)
+        r = _embed_mix_fwd(tokens, tok_table.detach(), None if byte_table is None else byte_table.detach(),
+                           scale_tok=None if scale_tok is None else scale_tok.detach(),
+                           scale_byte=None if scale_byte is None else scale_byte.detach(),
+                           return_ids=want_ids or user_return_ids, **kw)
+        x = r.x if isinstance(r, MixResult) else r
+        ids_a, ids_b = kw.get("ids_a"), kw.get("ids_b")
+        if want_ids:   # the byte ids the kernel produced in LDS, written out once for the backward
+            ids_a = r.ids_pulled if kw.get("pull") not in (None, "none") else r.ids_padded
+            ids_b = r.ids_padded if kw.get("add_padded") else None
+        ctx.save_for_backward(tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b)
+        ctx.kw = {k: kw[k] for k in ("mode", "bpt", "norm_tok", "norm_byte", "norm_out", "eps") if k in kw}
+        if user_return_ids:
+            ctx.mark_non_differentiable(r.ids_padded, r.ids_pulled)
+            return x, r.ids_padded, r.ids_pulled
+        return x
+
+    @staticmethod
+    def backward(ctx, gx, *_):
+        tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b = ctx.saved_tensors
+        g = embed_mix_backward(gx, tokens, tok_table.detach(), None if byte_table is None else byte_table.detach(),
+                               ids_a=ids_a, ids_b=ids_b,
+                               scale_tok=None if scale_tok is None else scale_tok.detach(),
+                               scale_byte=None if scale_byte is None else scale_byte.detach(), **ctx.kw)
+        return (g["tok_table"], g["byte_table"],
+                None if scale_tok is None else g["scale_tok"].reshape(scale_tok.shape),
+                None if scale_byte is None else g["scale_byte"].reshape(scale_byte.shape), None, None)
+
+
+@torch.compiler.disable
+def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor | None = None, *,
+                       mode: str, bpt: int = 0, ids_a: torch.Tensor | None = None, ids_b: torch.Tensor | None = None,
+                       norm_tok: bool = False, norm_byte: bool = False, norm_out: bool = False, eps: float | None = None,
+                       scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
+                       into: dict | None = None) -> dict:
+    """One launch of mot_embed_mix_bwd.  Returns dense fp32 gradients {tok_table, byte_table, scale_tok,
+    scale_byte}; pass `into` (same keys) to accumulate into existing buffers such as ``param.grad``."""
+    m = _MODES[mode]
+    if tokens.ndim == 1:
+        tokens = tokens[None]
+    dev = capi.require_device(grad_out, tokens, tok_table, byte_table, ids_a, ids_b, scale_tok, scale_byte)
+    tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
+    tok = tok if tok.is_contiguous() else tok.contiguous()
+    B, T = tok.shape
+    tt = _contig(tok_table, torch.float32, "tok_table")
+    g = _contig(grad_out, torch.float32, "grad_out")
+    d = capi.MotEmbedMixDesc()
+    d.struct_size = C.sizeof(capi.MotEmbedMixDesc)
+    d.dtype = capi.F32
+    d.n_rows, d.tokens_per_row, d.bpt, d.mode = B, T, int(bpt), m
+    d.tokens = capi.ptr(tok)
+    d.tok_table, d.tok_rows, d.tok_dim, d.model_dim = capi.ptr(tt), tt.shape[0], tt.shape[1], tt.shape[1]
+    into = into or {}
+    out = {"tok_table": into.get("tok_table", None), "byte_table": into.get("byte_table", None),
+           "scale_tok": into.get("scale_tok", None), "scale_byte": into.get("scale_byte", None)}
+    if out["tok_table"] is None:
+        out["tok_table"] = torch.zeros_like(tt)
+    keep = [tok, tt, g]
+    gr = capi.MotEmbedMixGrads()
+    gr.struct_size = C.sizeof(capi.MotEmbedMixGrads)
+    gr.grad_out = capi.ptr(g)
+    gr.d_tok_table = capi.ptr(out["tok_table"])
+    if m != capi.MIX_NOOP:
+        bt = _contig(byte_table, torch.float32, "byte_table")
+        ia = _contig(ids_a, torch.int64, "ids_a")
+        keep += [bt, ia]
+        d.byte_table, d.byte_rows, d.byte_dim = capi.ptr(bt), bt.shape[0], bt.shape[1]
+        d.id_source, d.ids_a = capi.IDS_GIVEN, capi.ptr(ia)
+        if ids_b is not None:
+            ib = _contig(ids_b, torch.int64, "ids_b")
+            keep.append(ib)
+            d.ids_b = capi.ptr(ib)
+        if out["byte_table"] is None:
+            out["byte_table"] = torch.zeros_like(bt)
+        gr.d_byte_table = capi.ptr(out["byte_table"])
+    d.norm_tok, d.norm_byte, d.norm_out = int(norm_tok), int(norm_byte), int(norm_out)
+    d.eps = float(eps or 0.0)
+    d.scale_tok, d.scale_byte = capi.ptr(scale_tok), capi.ptr(scale_byte)
+    for k, sc in (("scale_tok", scale_tok), ("scale_byte", scale_byte)):
+        if sc is not None and out[k] is None:
+            out[k] = torch.zeros(1, dtype=torch.float32, device=dev)
+    gr.d_scale_tok, gr.d_scale_byte = capi.ptr(out["scale_tok"]), capi.ptr(out["scale_byte"])
+    d.status = capi.ptr(capi.status_word(dev))
+    ws = _workspace(dev, capi.lib.mot_embed_mix_bwd_workspace_bytes(C.byref(d)))
+    if ws is not None:
+        d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
+    capi.check(capi.lib.mot_embed_mix_bwd(C.byref(d), C.byref(gr), capi.stream_of(dev)))
+    capi.after_call(dev)
+    return out
+
+
+def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor | None = None, *,
+              scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None, **kw):
+    """The fused front-end (see `_embed_mix_fwd` for the arguments).  With autograd enabled and
+    differentiable parameters it records one backward node (modes "sum" and "noop"; the
+    concat+linear backward is a later scope row and raises)."""
+    params = (tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"))
+    if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
+        if kw["mode"] not in _BWD_MODES:
+            raise RuntimeError(
+                f"mixture-of-tokenizers_amd: backward of mode '{kw['mode']}' is not built yet (forward only); "
+                "call it under torch.no_grad() or with frozen parameters")
+        if kw.get("out") is not None or kw.get("counters") is not None:
+            raise ValueError("out= / counters= cannot be combined with autograd")
+        r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, tokens, kw)
+        if kw.get("return_ids"):
+            return MixResult(*r)
+        return r
+    return _embed_mix_fwd(tokens, tok_table, byte_table, scale_tok=scale_tok, scale_byte=scale_byte, **kw)

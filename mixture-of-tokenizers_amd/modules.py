@@ -18,8 +18,10 @@ mixes and writes x.  Anything that needs the tensors themselves calls ``handle.m
 Parameters are read from their live storage at launch time, so weight tying
 (``wte.weight = lm_head.weight``, model.py:316-317) and in-place optimizer updates are honoured.
 
-Forward only (backward is the next row): calling these modules with autograd
-enabled on parameters that require grad raises instead of silently dropping the graph.
+Autograd: the gather + sum family (SumFrontEnd, the tokens-only / noop paths) is differentiable --
+one fused backward launch produces the dense table gradients.  The concat + linear mixin is forward
+only this round: with autograd enabled on parameters that require grad it raises instead of silently
+dropping the graph.
 """
 from __future__ import annotations
 
@@ -188,7 +190,6 @@ class ByteMixinNoop(nn.Module):  # train_gpt.py:421-427
 
     def forward(self, x, *args):
         if isinstance(x, EmbedHandle):
-            _check_forward_only(x.tok_weight)
             return F_mot.embed_mix(x.tokens, _f32(x.tok_weight, "token table"), mode="noop", norm_tok=x.norm_tok,
                                    scale_tok=x.scale_tok)
         return x
@@ -322,7 +323,6 @@ class DigitMixinNoOp(nn.Module):  # model.py:271-276
 
     def forward(self, x, *args):
         if isinstance(x, EmbedHandle):
-            _check_forward_only(x.tok_weight)
             return F_mot.embed_mix(x.tokens, _f32(x.tok_weight, "token table"), mode="noop")
         return x
 
@@ -376,7 +376,6 @@ class SumFrontEnd(nn.Module):
     def forward(self, token_inputs: Tensor, byte_inputs: Tensor | None = None) -> Tensor:
         """token_inputs (T,) or (B,T); byte_inputs (.., T*bpt) per-token-ordered pulled ids, or None to
         produce them in-kernel from the attached token->byte table."""
-        _check_forward_only(self.embed_tokens.weight, self.embed_bytes.weight, self.scalars)
         pre = self.variant != "71"
         kw = dict(norm_tok=pre, norm_byte=pre, norm_out=self.variant != "71081")
         if pre:

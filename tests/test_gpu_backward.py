@@ -1,0 +1,130 @@
+"""-m gpu: backward of the fused front-end (SUM / NOOP family) vs the gradients autograd left on the
+reference modules (tests/golden/grads.npz) and vs the float64 oracle.
+
+Tolerance: gradients are sums of up to thousands of fp32 contributions added with float atomics
+(order-dependent, as in the reference's own GPU embedding backward), so the bar is relative to the
+largest entry of each gradient tensor:  max|hip - ref64| <= 2e-5 * max|ref64|  (the reference's own
+fp32 CPU gradients sit at ~1e-6..1e-5 of that scale from its float64 gradients)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import oracle as orc
+from util_gpu import DEV, dev, f32, host
+
+pytestmark = pytest.mark.gpu
+G = gi.GOLDEN_DIR
+TOL = 2e-5
+
+
+def rel(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def mot():
+    import mixture_of_tokenizers_amd as m
+    return m
+
+
+SUM_SMALL = ("small", 97, 64, 8, 8, 40, 501)
+
+
+@pytest.mark.parametrize("variant", ["r71", "r71041", "r71081"])
+@pytest.mark.parametrize("source", ["ttb", "given"])
+def test_sum_backward_vs_reference_autograd(mot, variant, source):
+    """loss.backward() through SumFrontEnd == what autograd gives for the reference's run-71 family."""
+    from mixture_of_tokenizers_amd.modules import SumFrontEnd
+    name, Vt, D, Db, bpt, T, seed = SUM_SMALL
+    z = np.load(G / "grads.npz")
+    toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    fe = SumFrontEnd(Vt, gi.BYTE_VOCAB, D, Db, bpt, variant=variant[1:], ttb=dev(tab)).to(DEV)
+    with torch.no_grad():
+        fe.embed_tokens.weight.copy_(dev(f32(gi.normal_table(seed + 1, Vt, D))))
+        fe.embed_bytes.weight.copy_(dev(f32(gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db))))
+        if fe.scalars is not None:
+            fe.scalars.copy_(torch.tensor([0.75, 1.25], device=DEV))
+    if source == "ttb":
+        x = fe(dev(toks)[0])
+    else:
+        pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+        x = fe(dev(toks)[0], dev(pulled))
+    assert x.requires_grad
+    (x * dev(f32(z["sum/g"]))).sum().backward()                  # train_gpt.py:1319 / main.py:304
+    assert rel(host(fe.embed_tokens.weight.grad), z[f"sum/{variant}/f64/d_tok"]) < TOL
+    assert rel(host(fe.embed_bytes.weight.grad), z[f"sum/{variant}/f64/d_byte"]) < TOL
+    if fe.scalars is not None:
+        assert rel(host(fe.scalars.grad), z[f"sum/{variant}/f64/d_scalars"]) < TOL
+    # second backward accumulates into .grad like any torch parameter
+    (fe(dev(toks)[0]) * dev(f32(z["sum/g"]))).sum().backward()
+    assert rel(host(fe.embed_tokens.weight.grad), 2 * z[f"sum/{variant}/f64/d_tok"]) < TOL
+
+
+def test_noop_backward_vs_reference_autograd(mot):
+    """FlexibleEmbedding tokens-only mode + ByteMixinNoop (train_gpt.py:342-348, 421-427) under autograd."""
+    from mixture_of_tokenizers_amd import modules as M
+    name, Vt, Dt, Db, Dm, bpt, B, T, seed = ("small", 97, 32, 8, 64, 8, 2, 16, 401)
+    z = np.load(G / "grads.npz")
+    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="noop")
+    dims = M.ModelDims(model_dim=Dt, byte_dim=Db, token_dim=Dt)
+    embed, mixin = M.FlexibleEmbedding(dims, Vt, bp).to(DEV), M.ByteMixin(dims, T, bp).to(DEV)
+    with torch.no_grad():
+        embed.embed_tokens.weight.copy_(dev(f32(gi.normal_table(seed + 1, Vt, Dt))))
+    toks = dev(gi.edge_tokens(seed, B, T, Vt, eot_p=0.08))
+    x = mixin(*embed(tokens=toks, byte_tensor=None, byte_tensor_pulled=None))
+    (x * dev(f32(z["scaled/g_noop"]))).sum().backward()
+    assert rel(host(embed.embed_tokens.weight.grad), z["scaled/noop/f64/d_tok"]) < TOL
+
+
+def test_concat_backward_is_refused_loudly(mot):
+    from mixture_of_tokenizers_amd import modules as M
+    bp = M.ByteHyperparameters(bytes_per_token=8, byte_mixin_method="concat")
+    dims = M.ModelDims(model_dim=64, byte_dim=8, token_dim=32)
+    embed, mixin = M.FlexibleEmbedding(dims, 97, bp).to(DEV), M.ByteMixin(dims, 16, bp).to(DEV)
+    toks = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
+    ids = torch.zeros((1, 32), dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError, match="forward"):
+        mixin(*embed(toks, ids, ids))
+
+
+@pytest.mark.parametrize("D,Db,bpt,Vt,B,T,kw,seed", [
+    (768, 48, 16, 4096, 4, 512, dict(norm_out=True), 9101),                                   # headline dims
+    (768, 48, 16, 4096, 2, 300, dict(norm_tok=True, norm_byte=True, norm_out=True, scaled=True), 9102),
+    (256, 32, 8, 512, 3, 200, dict(), 9103),                                                  # no norms at all
+    (1024, 64, 16, 512, 2, 130, dict(norm_tok=True, norm_byte=True, scaled=True), 9104),      # 71081 shape
+    (240, 12, 20, 300, 2, 100, dict(norm_out=True), 9105),                                    # D % 64 != 0
+    (2048, 128, 16, 512, 1, 70, dict(norm_out=True), 9106),
+])
+def test_sum_backward_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
+    kw = dict(kw)
+    scaled = kw.pop("scaled", False)
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left")
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    g = f32(np.random.RandomState(seed + 4).standard_normal((B, T, D)))
+    padded = orc.tokens_to_bytes(toks, tab.astype(np.float32))
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    okw, gkw = dict(kw), dict(kw)
+    if scaled:
+        okw.update(scale_tok=1.3, scale_byte=0.6)
+        gkw.update(scale_tok=torch.tensor([1.3], device=DEV), scale_byte=torch.tensor([0.6], device=DEV))
+    ref = orc.embed_mix_bwd(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
+                            mode="sum", bpt=bpt, dtype=np.float64, **okw)
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(pulled), **gkw)
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+    assert rel(host(got["byte_table"]), ref["byte_table"]) < TOL
+    if scaled:
+        assert abs(float(got["scale_tok"]) - ref["scales"][0]) < TOL * abs(ref["scales"]).max()
+        assert abs(float(got["scale_byte"]) - ref["scales"][1]) < TOL * abs(ref["scales"]).max()
+    # rows no token touched get exactly zero gradient
+    untouched = np.setdiff1d(np.arange(Vt), np.unique(toks))
+    assert not host(got["tok_table"])[untouched].any()
+    if not kw.get("norm_byte"):      # two id tensors: emb(padded) + emb(pulled)
+        ref2 = orc.embed_mix_bwd(toks, pulled, padded, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
+                                 mode="sum", bpt=bpt, dtype=np.float64, **okw)
+        got2 = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(pulled),
+                                                 ids_b=dev(padded), **gkw)
+        assert rel(host(got2["byte_table"]), ref2["byte_table"]) < TOL
