@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--ids", default="fused", choices=["fused", "given"],
                     help="fused: byte ids produced inside the kernel; given: int64 ids precomputed (module-level path)")
     ap.add_argument("--uniform-ids", action="store_true", help="uniform token ids (no-reuse worst case)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="table/output element type (compute is fp32)")
     ap.add_argument("--backward", action="store_true", help="also time the backward launch (sum workloads) and report it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -85,10 +86,9 @@ def make_inputs(wl, device, seed, uniform):
     return dict(toks=toks, chars=chars, tok_table=tok_table, byte_table=byte_table, ttb_kind="n/a")
 
 
-def algorithmic_bytes_per_token(wl, ids_mode):
+def algorithmic_bytes_per_token(wl, ids_mode, e=4):
     """fully fused R = 4 + 2*bpt + e*Dt, W = e*Dm; module-level path reads int64 ids."""
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
-    e = 4
     if mode == "concat_linear":
         return 4 + 2 * bpt + e * WORKLOADS[wl][8] + e * D
     if mode == "sum":
@@ -119,7 +119,7 @@ def cpu_baseline(wl, inp, seconds):
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
     cores = usable_cores()
     orc.set_threads(cores)
-    Et, Eb = inp["tok_table"].cpu().numpy(), inp["byte_table"].cpu().numpy()
+    Et, Eb = inp["tok_table"].float().cpu().numpy(), inp["byte_table"].float().cpu().numpy()
     rows = min(B, 32)
     toks = inp["toks"][:rows]
 
@@ -168,7 +168,13 @@ def main():
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
     inp = make_inputs(wl, device, seed=12345 + rank, uniform=args.uniform_ids)   # loader default seed, train_gpt.py:661
     toks = torch.from_numpy(inp["toks"]).to(device)
-    out = torch.empty((B, T, D), dtype=torch.float32, device=device)
+    esize = 4
+    if args.dtype == "bf16":
+        esize = 2
+        for k in ("tok_table", "byte_table", "weight"):
+            if inp.get(k) is not None:
+                inp[k] = inp[k].to(torch.bfloat16)
+    out = torch.empty((B, T, D), dtype=inp["tok_table"].dtype, device=device)
     counters = torch.zeros(4, dtype=torch.int64, device=device)
     if mode == "sum":
         tab = torch.from_numpy(inp["tab"]).to(device)
@@ -231,7 +237,7 @@ def main():
     total_tokens = tokens_per_step * world * args.steps
 
     if rank == 0:
-        bpt_alg = algorithmic_bytes_per_token(wl, args.ids)
+        bpt_alg = algorithmic_bytes_per_token(wl, args.ids, esize)
         launch_bytes = bpt_alg * tokens_per_step
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         traffic = None
@@ -249,7 +255,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32" if args.dtype == "f32" else "bf16 tables/output, f32 arithmetic", "data": "synthetic",
             "config": {"workload": f"{wl}: BxT={B}x{T} per GPU, vocab {vocab}, bpt {bpt}, d_model {D}, byte_dim {Db}, "
                                    f"mode {mode}+rmsnorm, ids {args.ids}, token ids "
                                    f"{'uniform' if args.uniform_ids else 'FineWeb-shaped (u^3 skew, EOT p=1/700)'}, "
@@ -269,7 +275,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "embed_mix_linear_kernel",
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
-        if args.backward and mode == "sum":
+        if args.backward and mode == "sum" and args.dtype == "f32":
             from mixture_of_tokenizers_amd import data_creation as dc
             ids_b = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
             gout = torch.randn_like(out)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 2
+#define MOT_ABI_VERSION 3
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -66,7 +66,11 @@ typedef enum MotIdSource {
     MOT_IDS_GIVEN = 2     /* ids_a (and ids_b) precomputed int64, as the reference loader emits  */
 } MotIdSource;
 
-typedef enum MotDType { MOT_F32 = 0 } MotDType;
+/* Element type of the tables, the weight and `out` (scalars, workspace and gradients stay fp32).
+ * MOT_BF16 is what the production loop runs (nn.Embedding -> bf16, train_gpt.py:1124-1126): rows are
+ * widened to fp32 on load, all arithmetic is fp32, results are rounded once (nearest-even) on store;
+ * eps defaults to torch.finfo(bfloat16).eps = 2^-7, as F.rms_norm(eps=None) does on bf16 inputs. */
+typedef enum MotDType { MOT_F32 = 0, MOT_BF16 = 1 } MotDType;
 
 int mot_version(void);                /* MOT_ABI_VERSION the library was built with */
 const char *mot_last_error(void);     /* host string, thread-local, never NULL      */
@@ -108,13 +112,14 @@ int mot_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *tt
  * Replaces emb(ids) / norm(emb(ids)) / norm(emb(ids_a) + emb(ids_b)) when the caller wants the
  * tensors at the FlexibleEmbedding seam materialised
  *                                                 scaled-pre-train/train_gpt.py:342-379, 172-173
- *   ids int64|int32 [n] (ids_elem_bytes 8|4), ids_b optional; table f32 [rows, dim];
- *   out f32 [n, dim]; rms_norm: x * rsqrt(mean(x^2) + eps), eps <= 0 -> FLT_EPSILON
+ *   ids int64|int32 [n] (ids_elem_bytes 8|4), ids_b optional; table f32|bf16 [rows, dim];
+ *   out (same type) [n, dim]; rms_norm: x * rsqrt(mean(x^2) + eps), eps <= 0 -> FLT_EPSILON
  *   (F.rms_norm eps=None); scale optional device scalar.
  */
 int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, int64_t n,
-                    const float *table, int64_t rows, int dim, int rms_norm, float eps,
-                    const float *scale, float *out, uint32_t *status, mot_stream_t stream);
+                    const void *table, int64_t rows, int dim, int rms_norm, float eps,
+                    const float *scale, void *out, uint32_t *status, int dtype /* MotDType */,
+                    mot_stream_t stream);
 
 /*
  * The fused front-end.  Replaces, in ONE launch (plus a 458-row prologue when norm_byte is set):

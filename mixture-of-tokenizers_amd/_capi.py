@@ -21,9 +21,17 @@ STATUS_TOKEN_OOR, STATUS_BYTE_OOR = 1, 2
 PULL_NONE, PULL_LEFT, PULL_RIGHT = 0, 1, 2
 MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
-F32 = 0
+F32, BF16 = 0, 1
 MAX_BPT = 64
-ABI_VERSION = 2
+ABI_VERSION = 3
+
+
+def dtype_code(t: torch.dtype) -> int:
+    if t == torch.float32:
+        return F32
+    if t == torch.bfloat16:
+        return BF16
+    raise TypeError(f"tables must be float32 or bfloat16, got {t}")
 
 EXPORTS = (
     "mot_version", "mot_last_error", "mot_build_info", "mot_tokens_to_bytes", "mot_pull_bytes",
@@ -74,7 +82,7 @@ def _load() -> C.CDLL:
     lib.mot_tokens_to_bytes.argtypes = [vp, i64, vp, i32, i64, i32, vp, vp, vp]
     lib.mot_pull_bytes.argtypes = [vp, vp, i64, i64, i32, i64, i64, i32, vp]
     lib.mot_create_batch.argtypes = [vp, i64, i64, vp, vp, i32, i64, i32, i64, i64, vp, vp, vp]
-    lib.mot_gather_rows.argtypes = [vp, vp, i32, i64, vp, i64, i32, i32, f32, vp, vp, vp, vp]
+    lib.mot_gather_rows.argtypes = [vp, vp, i32, i64, vp, i64, i32, i32, f32, vp, vp, vp, i32, vp]
     lib.mot_embed_mix_desc_size.restype = C.c_size_t
     lib.mot_embed_mix_workspace_bytes.restype = C.c_size_t
     lib.mot_embed_mix_workspace_bytes.argtypes = [C.POINTER(MotEmbedMixDesc)]

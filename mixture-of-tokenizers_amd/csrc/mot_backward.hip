@@ -364,7 +364,7 @@ int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, h
         const size_t tab = (size_t)d.byte_rows * d.byte_dim * sizeof(float);
         if (tab + lds <= 150 * 1024) { A.privatize = 1; lds += tab; }
         if (d.norm_byte) {
-            int rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rn, stream);
+            int rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rn, MOT_F32, stream);
             if (rc) return rc;
             A.byte_rnorm = rn;
         }

@@ -33,7 +33,9 @@ static int validate_embed_mix(const MotEmbedMixDesc *d) {
     if (!d) return set_error(MOT_EINVAL, "embed_mix: null descriptor");
     if (d->struct_size != sizeof(MotEmbedMixDesc))
         return set_error(MOT_EINVAL, "embed_mix: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(MotEmbedMixDesc));
-    if (d->dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "embed_mix: dtype %d (only MOT_F32 is built)", d->dtype);
+    if (d->dtype != MOT_F32 && d->dtype != MOT_BF16) return set_error(MOT_EINVAL, "embed_mix: bad dtype %d", d->dtype);
+    if (d->dtype == MOT_BF16 && d->mode == MOT_MIX_CONCAT_LINEAR)
+        return set_error(MOT_EUNSUPPORTED, "embed_mix: the bf16 concat_linear (bf16 MFMA) kernel is not built yet");
     if (d->n_rows < 0 || d->tokens_per_row < 0) return set_error(MOT_ESHAPE, "embed_mix: negative shape");
     if (d->mode < MOT_MIX_NOOP || d->mode > MOT_MIX_CONCAT_LINEAR) return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d->mode);
     if (!d->tokens || !d->tok_table || !d->out) return set_error(MOT_EINVAL, "embed_mix: tokens/tok_table/out must be non-null");
@@ -137,15 +139,16 @@ int mot_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *tt
                                (int32_t)eot_byte, out, status, (hipStream_t)stream);
 }
 
-int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, int64_t n, const float *table, int64_t rows,
-                    int dim, int rms_norm, float eps, const float *scale, float *out, uint32_t *status,
+int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, int64_t n, const void *table, int64_t rows,
+                    int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int dtype,
                     mot_stream_t stream) {
+    if (dtype != MOT_F32 && dtype != MOT_BF16) return set_error(MOT_EINVAL, "gather_rows: bad dtype %d", dtype);
     if (n < 0) return set_error(MOT_ESHAPE, "gather_rows: n < 0");
     if (n == 0) return MOT_OK;
     if (!ids_a || !table || !out) return set_error(MOT_EINVAL, "gather_rows: null pointer");
     if (ids_elem_bytes != 4 && ids_elem_bytes != 8) return set_error(MOT_EINVAL, "gather_rows: ids_elem_bytes must be 4 or 8");
     if (rows <= 0 || dim <= 0) return set_error(MOT_ESHAPE, "gather_rows: empty table");
-    return launch_gather_rows(ids_a, ids_b, ids_elem_bytes, n, table, rows, dim, rms_norm, eps, scale, out, status,
+    return launch_gather_rows(ids_a, ids_b, ids_elem_bytes, n, table, rows, dim, rms_norm, eps, scale, out, status, dtype,
                               (hipStream_t)stream);
 }
 
@@ -170,6 +173,7 @@ int mot_embed_mix_bwd(const MotEmbedMixDesc *desc, const MotEmbedMixGrads *grads
     if (!d.out) d.out = (void *)grads->grad_out;  // the forward validator wants a non-null `out`; it is not touched
     int rc = validate_embed_mix(&d);
     if (rc) return rc;
+    if (d.dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: only MOT_F32 is built");
     if (!grads->grad_out) return set_error(MOT_EINVAL, "embed_mix_bwd: grad_out missing");
     if (!grads->d_tok_table) return set_error(MOT_EINVAL, "embed_mix_bwd: d_tok_table missing");
     if (d.mode == MOT_MIX_SUM && !grads->d_byte_table) return set_error(MOT_EINVAL, "embed_mix_bwd: d_byte_table missing");

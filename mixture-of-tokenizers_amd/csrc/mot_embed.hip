@@ -18,8 +18,9 @@ namespace mot {
 // ------------------------------------------------------------------------------------------ fused kernel
 // MODE: MOT_MIX_NOOP / SUM / MEAN.   NCH: float4 chunks per lane (covers Dm <= 256*NCH).
 // U: tokens in flight per wave.
-template <int MODE, int NCH, int U>
+template <int MODE, int NCH, int U, typename T>
 __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
+    const T *tok_table = (const T *)A.tok_table, *byte_table = (const T *)A.byte_table;
     extern __shared__ int32_t lds[];
     const bool has_ids = MODE != MOT_MIX_NOOP;
     const TileLds L = tile_lds_carve(lds, A.tile_tokens, has_ids ? A.bpt : 1, true);
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     const bool scale_t = A.scale_tok != nullptr, scale_b = A.scale_byte != nullptr;
-    float *orow = A.out + (row * A.T + t0) * (int64_t)Dm;
+    T *orow = (T *)A.out + (row * A.T + t0) * (int64_t)Dm;
 
     for (int tb = wave * U; tb < ntok; tb += kWaves * U) {
         float4v a[U][NCH], b[U][NCH];
@@ -75,16 +76,16 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
                 if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
                 tok = 0;
             }
-            const float *trow = A.tok_table + (int64_t)tok * Dm;
+            const T *trow = tok_table + (int64_t)tok * Dm;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                a[u][i] = act[i] ? *(const float4v *)(trow + 4 * (lane + 64 * i)) : (float4v)(0.f);
+                a[u][i] = act[i] ? Elem<T>::load4(trow + 4 * (lane + 64 * i)) : (float4v)(0.f);
                 if (MODE == MOT_MIX_SUM) {
                     const int id = L.ids[t * sv + slot[i]];
-                    float4v v = *(const float4v *)(A.byte_table + (int64_t)id * A.Db + within[i]);
+                    float4v v = Elem<T>::load4(byte_table + (int64_t)id * A.Db + within[i]);
                     if (dual) {  // norm(emb(padded) + emb(pulled)) without the norm (train_gpt.py:378)
                         const int id2 = L.val[t * sv + slot[i]];
-                        v += *(const float4v *)(A.byte_table + (int64_t)id2 * A.Db + within[i]);
+                        v += Elem<T>::load4(byte_table + (int64_t)id2 * A.Db + within[i]);
                     }
                     if (A.norm_byte) v *= A.byte_rnorm[id];
                     b[u][i] = v;
@@ -92,10 +93,10 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
                     float4v acc = (float4v)(0.f);
                     for (int k = 0; k < A.bpt; ++k) {  // chars.mean(dim=-2), inference.py:267
                         const int id = L.ids[t * sv + k];
-                        float4v v = *(const float4v *)(A.byte_table + (int64_t)id * A.Db + within[i]);
+                        float4v v = Elem<T>::load4(byte_table + (int64_t)id * A.Db + within[i]);
                         if (dual) {
                             const int id2 = L.val[t * sv + k];
-                            v += *(const float4v *)(A.byte_table + (int64_t)id2 * A.Db + within[i]);
+                            v += Elem<T>::load4(byte_table + (int64_t)id2 * A.Db + within[i]);
                         }
                         if (A.norm_byte) v *= A.byte_rnorm[id];
                         acc += v;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
             if (t < ntok) {
 #pragma unroll
                 for (int i = 0; i < NCH; ++i)
-                    if (act[i]) __builtin_nontemporal_store(x[i], (float4v *)(orow + (int64_t)t * Dm + 4 * (lane + 64 * i)));
+                    if (act[i]) Elem<T>::store4_nt(orow + (int64_t)t * Dm + 4 * (lane + 64 * i), x[i]);
             }
         }
     }
@@ -147,14 +148,15 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
 // byte_rnorm[r] = rsqrt(mean(byte_table[r]^2) + eps): rms-norm of a gathered byte row depends on
 // the row only, so the per-slot reduction of norm(embed_bytes(ids)) (train_gpt.py:357,368)
 // collapses to one multiply in the fused kernel.  One wave per table row.
-__global__ __launch_bounds__(kThreads) void rows_rnorm_kernel(const float *__restrict__ table, int64_t rows, int dim,
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rows_rnorm_kernel(const T *__restrict__ table, int64_t rows, int dim,
                                                               float eps, float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     if (r >= rows) return;
     float ss = 0.f;
     for (int j = lane; j < dim; j += 64) {
-        const float v = table[r * dim + j];
+        const float v = Elem<T>::load1(table + r * dim + j);
         ss += v * v;
     }
     ss = wave_sum(ss);
@@ -164,11 +166,11 @@ __global__ __launch_bounds__(kThreads) void rows_rnorm_kernel(const float *__res
 // ------------------------------------------------------------------------------------------ seam gather
 // out[n] = scale * rms_norm?(table[idsA[n]] (+ table[idsB[n]])): the tensors FlexibleEmbedding.forward
 // returns (train_gpt.py:342-379).  G lanes cooperate on a row (G = 8..64 by row length).
-template <int G, typename IdT>
+template <int G, typename IdT, typename T>
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const IdT *__restrict__ ids_a, const IdT *__restrict__ ids_b,
-                                                               int64_t n, const float *__restrict__ table, int64_t rows,
+                                                               int64_t n, const T *__restrict__ table, int64_t rows,
                                                                int dim, int rms, float eps, const float *scale,
-                                                               float *__restrict__ out, uint32_t *status) {
+                                                               T *__restrict__ out, uint32_t *status) {
     const int g = threadIdx.x % G;
     const int64_t per_block = kThreads / G;
     const float s = scale ? *scale : 1.0f;
@@ -180,21 +182,21 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const IdT *__rest
             if ((uint64_t)ia >= (uint64_t)rows) ia = 0;
             if ((uint64_t)ib >= (uint64_t)rows) ib = 0;
         }
-        const float *pa = table + ia * dim, *pb = table + ib * dim;
-        float *po = out + r * dim;
+        const T *pa = table + ia * dim, *pb = table + ib * dim;
+        T *po = out + r * dim;
         float mult = s;
         if (rms) {
             float ss = 0.f;
             if (vec) {
                 for (int j = g; j < (dim >> 2); j += G) {
-                    float4v v = *(const float4v *)(pa + 4 * j);
-                    if (ids_b) v += *(const float4v *)(pb + 4 * j);
+                    float4v v = Elem<T>::load4(pa + 4 * j);
+                    if (ids_b) v += Elem<T>::load4(pb + 4 * j);
                     ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
                 }
             } else {
                 for (int j = g; j < dim; j += G) {
-                    float v = pa[j];
-                    if (ids_b) v += pb[j];
+                    float v = Elem<T>::load1(pa + j);
+                    if (ids_b) v += Elem<T>::load1(pb + j);
                     ss += v * v;
                 }
             }
@@ -204,56 +206,66 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const IdT *__rest
         }
         if (vec) {
             for (int j = g; j < (dim >> 2); j += G) {
-                float4v v = *(const float4v *)(pa + 4 * j);
-                if (ids_b) v += *(const float4v *)(pb + 4 * j);
+                float4v v = Elem<T>::load4(pa + 4 * j);
+                if (ids_b) v += Elem<T>::load4(pb + 4 * j);
                 if (rms) v *= mult;
                 if (scale) v *= s;
-                __builtin_nontemporal_store(v, (float4v *)(po + 4 * j));
+                Elem<T>::store4_nt(po + 4 * j, v);
             }
         } else {
             for (int j = g; j < dim; j += G) {
-                float v = pa[j];
-                if (ids_b) v += pb[j];
+                float v = Elem<T>::load1(pa + j);
+                if (ids_b) v += Elem<T>::load1(pb + j);
                 if (rms) v *= mult;
                 if (scale) v *= s;
-                po[j] = v;
+                Elem<T>::store1(po + j, v);
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------ launchers
-template <int G>
-static int launch_gather_g(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const float *table,
-                           int64_t rows, int dim, int rms, float eps, const float *scale, float *out, uint32_t *status,
+template <int G, typename T>
+static int launch_gather_g(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table,
+                           int64_t rows, int dim, int rms, float eps, const float *scale, void *out, uint32_t *status,
                            hipStream_t stream) {
     const int64_t per_block = kThreads / G;
     int64_t blocks = (n + per_block - 1) / per_block;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (ids_elem == 8)
-        hipLaunchKernelGGL((gather_rows_kernel<G, int64_t>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
-                           (const int64_t *)ids_a, (const int64_t *)ids_b, n, table, rows, dim, rms, eps, scale, out, status);
+        hipLaunchKernelGGL((gather_rows_kernel<G, int64_t, T>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
+                           (const int64_t *)ids_a, (const int64_t *)ids_b, n, (const T *)table, rows, dim, rms, eps, scale, (T *)out, status);
     else
-        hipLaunchKernelGGL((gather_rows_kernel<G, int32_t>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
-                           (const int32_t *)ids_a, (const int32_t *)ids_b, n, table, rows, dim, rms, eps, scale, out, status);
+        hipLaunchKernelGGL((gather_rows_kernel<G, int32_t, T>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
+                           (const int32_t *)ids_a, (const int32_t *)ids_b, n, (const T *)table, rows, dim, rms, eps, scale, (T *)out, status);
     return check_launch("gather_rows_kernel");
 }
 
-int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const float *table, int64_t rows,
-                       int dim, int rms_norm, float eps, const float *scale, float *out, uint32_t *status,
-                       hipStream_t stream) {
-    if (n == 0) return MOT_OK;
-    if (eps <= 0.f) eps = FLT_EPSILON;
+template <typename T>
+static int launch_gather_t(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
+                           int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, hipStream_t stream) {
     const int lanes = (dim & 3) == 0 ? dim / 4 : dim;
-    if (lanes <= 8) return launch_gather_g<8>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
-    if (lanes <= 16) return launch_gather_g<16>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
-    if (lanes <= 32) return launch_gather_g<32>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
-    return launch_gather_g<64>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    if (lanes <= 8) return launch_gather_g<8, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    if (lanes <= 16) return launch_gather_g<16, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    if (lanes <= 32) return launch_gather_g<32, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    return launch_gather_g<64, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
 }
 
-int launch_rows_rnorm(const float *table, int64_t rows, int dim, float eps, float *out, hipStream_t stream) {
+int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
+                       int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int dtype,
+                       hipStream_t stream) {
+    if (n == 0) return MOT_OK;
+    if (eps <= 0.f) eps = dtype == MOT_BF16 ? 0.0078125f : FLT_EPSILON;
+    if (dtype == MOT_BF16) return launch_gather_t<__bf16>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    return launch_gather_t<float>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+}
+
+int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float *out, int dtype, hipStream_t stream) {
     const int64_t rb = (rows + kWaves - 1) / kWaves;
-    hipLaunchKernelGGL(rows_rnorm_kernel, dim3((unsigned)rb), dim3(kThreads), 0, stream, table, rows, dim, eps, out);
+    if (dtype == MOT_BF16)
+        hipLaunchKernelGGL(rows_rnorm_kernel<__bf16>, dim3((unsigned)rb), dim3(kThreads), 0, stream, (const __bf16 *)table, rows, dim, eps, out);
+    else
+        hipLaunchKernelGGL(rows_rnorm_kernel<float>, dim3((unsigned)rb), dim3(kThreads), 0, stream, (const float *)table, rows, dim, eps, out);
     return check_launch("rows_rnorm_kernel");
 }
 
@@ -264,22 +276,25 @@ size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d) {
 }
 
 template <int MODE, int NCH, int U>
-static int launch_mix(const MixArgs &A, int64_t blocks, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
+static int launch_mix(const MixArgs &A, int dtype, int64_t blocks, size_t lds, hipStream_t stream) {
+    if (dtype == MOT_BF16)
+        hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U, __bf16>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
+    else
+        hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U, float>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
     return check_launch("embed_mix_kernel");
 }
 
 template <int MODE>
-static int dispatch_nch(const MixArgs &A, int nch, int64_t blocks, size_t lds, hipStream_t stream) {
+static int dispatch_nch(const MixArgs &A, int dtype, int nch, int64_t blocks, size_t lds, hipStream_t stream) {
     switch (nch) {
-        case 1: return launch_mix<MODE, 1, 4>(A, blocks, lds, stream);
-        case 2: return launch_mix<MODE, 2, 4>(A, blocks, lds, stream);
-        case 3: return launch_mix<MODE, 3, 2>(A, blocks, lds, stream);
-        case 4: return launch_mix<MODE, 4, 2>(A, blocks, lds, stream);
+        case 1: return launch_mix<MODE, 1, 4>(A, dtype, blocks, lds, stream);
+        case 2: return launch_mix<MODE, 2, 4>(A, dtype, blocks, lds, stream);
+        case 3: return launch_mix<MODE, 3, 2>(A, dtype, blocks, lds, stream);
+        case 4: return launch_mix<MODE, 4, 2>(A, dtype, blocks, lds, stream);
         case 5:
-        case 6: return launch_mix<MODE, 6, 1>(A, blocks, lds, stream);
+        case 6: return launch_mix<MODE, 6, 1>(A, dtype, blocks, lds, stream);
         case 7:
-        case 8: return launch_mix<MODE, 8, 1>(A, blocks, lds, stream);
+        case 8: return launch_mix<MODE, 8, 1>(A, dtype, blocks, lds, stream);
         default: return set_error(MOT_EUNSUPPORTED, "embed_mix: model_dim %d > 2048 is not built", A.Dt);
     }
 }
@@ -301,15 +316,15 @@ int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
         if (!d.workspace || d.workspace_bytes < need)
             return set_error(MOT_EWORKSPACE, "embed_mix: norm_byte needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
         float *rn = (float *)d.workspace;
-        int rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rn, stream);
+        int rc = launch_rows_rnorm(d.byte_table, d.byte_rows, d.byte_dim, A.eps, rn, d.dtype, stream);
         if (rc) return rc;
         A.byte_rnorm = rn;
     }
     const int nch = (d.tok_dim / 4 + 63) / 64;
     switch (d.mode) {
-        case MOT_MIX_NOOP: return dispatch_nch<MOT_MIX_NOOP>(A, nch, blocks, lds, stream);
-        case MOT_MIX_SUM: return dispatch_nch<MOT_MIX_SUM>(A, nch, blocks, lds, stream);
-        case MOT_MIX_MEAN: return dispatch_nch<MOT_MIX_MEAN>(A, nch, blocks, lds, stream);
+        case MOT_MIX_NOOP: return dispatch_nch<MOT_MIX_NOOP>(A, d.dtype, nch, blocks, lds, stream);
+        case MOT_MIX_SUM: return dispatch_nch<MOT_MIX_SUM>(A, d.dtype, nch, blocks, lds, stream);
+        case MOT_MIX_MEAN: return dispatch_nch<MOT_MIX_MEAN>(A, d.dtype, nch, blocks, lds, stream);
         default: return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d.mode);
     }
 }

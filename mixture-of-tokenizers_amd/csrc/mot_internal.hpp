@@ -21,10 +21,10 @@ int launch_pull_bytes(const int64_t *in, int64_t *out, int64_t B, int64_t tokens
 int launch_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *ttb_left, const void *ttb_right,
                         int elem, int64_t ttb_rows, int bpt, int32_t pad, int32_t eot, int64_t *out, uint32_t *status,
                         hipStream_t stream);
-int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const float *table, int64_t rows,
-                       int dim, int rms_norm, float eps, const float *scale, float *out, uint32_t *status,
+int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
+                       int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int dtype,
                        hipStream_t stream);
-int launch_rows_rnorm(const float *table, int64_t rows, int dim, float eps, float *out, hipStream_t stream);
+int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float *out, int dtype, hipStream_t stream);
 size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream);         // SUM / MEAN / NOOP
 int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream);  // CONCAT_LINEAR

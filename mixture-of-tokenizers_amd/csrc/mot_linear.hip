@@ -396,7 +396,7 @@ int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) {
     int rc = check_launch("transpose_pad_kernel");
     if (rc) return rc;
     if (d.norm_byte && !P.dual) {
-        rc = launch_rows_rnorm(P.M.byte_table, d.byte_rows, d.byte_dim, P.M.eps, rn, stream);
+        rc = launch_rows_rnorm(P.M.byte_table, d.byte_rows, d.byte_dim, P.M.eps, rn, MOT_F32, stream);
         if (rc) return rc;
         P.M.byte_rnorm = rn;
     }

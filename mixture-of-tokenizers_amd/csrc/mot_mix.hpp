@@ -10,6 +10,23 @@
 namespace mot {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+
+// Element access for the two table/output formats.  All arithmetic is fp32; bf16 rows are widened on
+// load (8 B per lane-chunk) and results rounded once, to nearest-even, on store (v_cvt_pk_bf16_f32).
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static __device__ __forceinline__ float4v load4(const float *p) { return *(const float4v *)p; }
+    static __device__ __forceinline__ float load1(const float *p) { return *p; }
+    static __device__ __forceinline__ void store4_nt(float *p, float4v v) { __builtin_nontemporal_store(v, (float4v *)p); }
+    static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
+};
+template <> struct Elem<__bf16> {
+    static __device__ __forceinline__ float4v load4(const __bf16 *p) { return __builtin_convertvector(*(const bf16x4v *)p, float4v); }
+    static __device__ __forceinline__ float load1(const __bf16 *p) { return (float)*p; }
+    static __device__ __forceinline__ void store4_nt(__bf16 *p, float4v v) { __builtin_nontemporal_store(__builtin_convertvector(v, bf16x4v), (bf16x4v *)p); }
+    static __device__ __forceinline__ void store1(__bf16 *p, float v) { *p = (__bf16)v; }
+};
 
 struct MixArgs {
     // ids
@@ -137,7 +154,8 @@ inline void fill_mix_args(MixArgs &A, const MotEmbedMixDesc &d) {
     A.tok_table = (const float *)d.tok_table; A.tok_rows = d.tok_rows; A.Dt = d.tok_dim;
     A.byte_table = (const float *)d.byte_table; A.byte_rows = d.byte_rows; A.Db = d.byte_dim;
     A.norm_tok = d.norm_tok; A.norm_byte = d.norm_byte; A.norm_out = d.norm_out;
-    A.eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    // F.rms_norm(eps=None) uses torch.finfo(x.dtype).eps: 2^-23 for fp32 inputs, 2^-7 for bf16 inputs
+    A.eps = d.eps > 0.f ? d.eps : (d.dtype == MOT_BF16 ? 0.0078125f : FLT_EPSILON);
     A.scale_tok = d.scale_tok; A.scale_byte = d.scale_byte;
     A.byte_rnorm = nullptr;
     A.out = (float *)d.out;

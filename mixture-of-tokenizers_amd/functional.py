@@ -24,6 +24,14 @@ def _contig(t: torch.Tensor, dtype: torch.dtype, what: str) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+def _table(t: torch.Tensor, what: str, like: torch.dtype | None = None) -> torch.Tensor:
+    """fp32 (parity mode) or bf16 (what the training loop runs) table; all tables of a call agree."""
+    capi.dtype_code(t.dtype)
+    if like is not None and t.dtype != like:
+        raise TypeError(f"{what}: {t.dtype} but the token table is {like}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
 def _int_table(table: torch.Tensor, what: str) -> torch.Tensor:
     if table.dtype not in (torch.int16, torch.int32):
         raise TypeError(f"{what}: token->byte table must be int16 or int32, got {table.dtype}")
@@ -87,7 +95,7 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor, ids_b: torch.Tensor | No
                 eps: float | None = None, scale: torch.Tensor | None = None) -> torch.Tensor:
     """scale * rms_norm?(table[ids] (+ table[ids_b])) -> ids.shape + (dim,)  (train_gpt.py:342-379)."""
     dev = capi.require_device(table, ids, ids_b, scale)
-    tab = _contig(table, torch.float32, "table")
+    tab = _table(table, "table")
     if ids.dtype not in (torch.int32, torch.int64):
         raise TypeError(f"ids must be int32/int64, got {ids.dtype}")
     ia = ids if ids.is_contiguous() else ids.contiguous()
@@ -96,10 +104,11 @@ def gather_rows(table: torch.Tensor, ids: torch.Tensor, ids_b: torch.Tensor | No
         if ids_b.shape != ids.shape or ids_b.dtype != ids.dtype:
             raise ValueError("ids_b must match ids in shape and dtype")
         ib = ids_b if ids_b.is_contiguous() else ids_b.contiguous()
-    out = torch.empty(ids.shape + (tab.shape[1],), dtype=torch.float32, device=dev)
+    out = torch.empty(ids.shape + (tab.shape[1],), dtype=tab.dtype, device=dev)
     capi.check(capi.lib.mot_gather_rows(capi.ptr(ia), capi.ptr(ib), ia.element_size(), ia.numel(), capi.ptr(tab),
                                         tab.shape[0], tab.shape[1], int(rms_norm), float(eps or 0.0), capi.ptr(scale),
-                                        capi.ptr(out), capi.ptr(capi.status_word(dev)), capi.stream_of(dev)))
+                                        capi.ptr(out), capi.ptr(capi.status_word(dev)), capi.dtype_code(tab.dtype),
+                                        capi.stream_of(dev)))
     capi.after_call(dev)
     return out
 
@@ -152,10 +161,11 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
     tok = tok if tok.is_contiguous() else tok.contiguous()
     B, T = tok.shape
-    tt = _contig(tok_table, torch.float32, "tok_table")
+    tt = _table(tok_table, "tok_table")
+    fdt = tt.dtype
     d = capi.MotEmbedMixDesc()
     d.struct_size = C.sizeof(capi.MotEmbedMixDesc)
-    d.dtype = capi.F32
+    d.dtype = capi.dtype_code(fdt)
     d.n_rows, d.tokens_per_row, d.bpt, d.mode = B, T, int(bpt), m
     d.tokens = capi.ptr(tok)
     d.tok_table, d.tok_rows, d.tok_dim = capi.ptr(tt), tt.shape[0], tt.shape[1]
@@ -164,7 +174,7 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     if m != capi.MIX_NOOP:
         if byte_table is None:
             raise ValueError("byte_table is required unless mode == 'noop'")
-        bt = _contig(byte_table, torch.float32, "byte_table")
+        bt = _table(byte_table, "byte_table", fdt)
         keep.append(bt)
         d.byte_table, d.byte_rows, d.byte_dim = capi.ptr(bt), bt.shape[0], bt.shape[1]
         if ttb is not None:
@@ -195,13 +205,13 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     if m == capi.MIX_CONCAT_LINEAR:
         if weight is None:
             raise ValueError("weight is required for mode == 'concat_linear'")
-        w = _contig(weight, torch.float32, "weight")
+        w = _table(weight, "weight", fdt)
         keep.append(w)
         d.weight, d.model_dim = capi.ptr(w), w.shape[0]
         if w.shape[1] != tt.shape[1] + bpt * d.byte_dim:
             raise ValueError(f"weight has {w.shape[1]} input features, expected {tt.shape[1]} + {bpt}*{d.byte_dim}")
         if bias is not None:
-            bs = _contig(bias, torch.float32, "bias")
+            bs = _table(bias, "bias", fdt)
             keep.append(bs)
             d.bias = capi.ptr(bs)
         d.bytes_first = int(bytes_first)
@@ -211,10 +221,10 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     d.eps = float(eps or 0.0)
     d.scale_tok, d.scale_byte = capi.ptr(scale_tok), capi.ptr(scale_byte)
     if out is None:
-        out = torch.empty((B, T, d.model_dim), dtype=torch.float32, device=dev)
+        out = torch.empty((B, T, d.model_dim), dtype=fdt, device=dev)
     else:
-        if out.shape != (B, T, d.model_dim) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
-            raise ValueError("out must be a contiguous float32 (B, T, model_dim) tensor on the inputs' device")
+        if out.shape != (B, T, d.model_dim) or out.dtype != fdt or not out.is_contiguous() or out.device != dev:
+            raise ValueError("out must be a contiguous (B, T, model_dim) tensor of the tables' dtype on their device")
     d.out = capi.ptr(out)
     if counters is not None:
         if counters.dtype != torch.int64 or counters.numel() < 4 or counters.device != dev:
@@ -347,6 +357,9 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
                 "call it under torch.no_grad() or with frozen parameters")
         if kw.get("out") is not None or kw.get("counters") is not None:
             raise ValueError("out= / counters= cannot be combined with autograd")
+        if tok_table.dtype != torch.float32:
+            raise RuntimeError("mixture-of-tokenizers_amd: the backward is built for float32 tables only; "
+                               "use torch.no_grad() with bfloat16 tables")
         r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, tokens, kw)
         if kw.get("return_ids"):
             return MixResult(*r)

@@ -111,8 +111,9 @@ def _check_forward_only(*params) -> None:
 
 
 def _f32(p: Tensor, what: str) -> Tensor:
-    if p.dtype != torch.float32:
-        raise NotImplementedError(f"{what} is {p.dtype}: only the fp32 parity mode is built (bf16 tables are a later row)")
+    """fp32 (parity mode) and bf16 (the production cast, train_gpt.py:1124-1126) tables are built."""
+    if p.dtype not in (torch.float32, torch.bfloat16):
+        raise NotImplementedError(f"{what} is {p.dtype}: only float32 and bfloat16 are built")
     return p
 
 

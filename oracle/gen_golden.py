@@ -476,6 +476,30 @@ def gen_grads(dc, tg, r71, mmodel):
     print("grads:", len(out), "arrays")
 
 
+# ------------------------------------------------------------------ bf16 (the dtype the training loop runs)
+def gen_bf16(dc, tg, r71):
+    """The same modules with bf16 tables, eager on CPU (train_gpt.py:1124-1126 casts nn.Embedding to bf16;
+    runs/7*.py do the same).  Outputs are bf16, stored widened to float32 (exact)."""
+    out = {}
+    norm, mixin_bytes = r71["norm"], r71["mixin_bytes"]
+    name, Vt, D, Db, bpt, T, seed = SUM_CASES[1]
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+    pulled = dc.pull_from_left(dc.tokens_to_bytes(torch.from_numpy(toks), ttb_embedding(tab)), bpt, gi.PAD, gi.EOT)
+    byte_inputs = pulled.view(T, bpt).t().contiguous()
+    et = torch.from_numpy(gi.normal_table(seed + 1, Vt, D)).bfloat16()
+    eb = torch.from_numpy(gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db)).bfloat16()
+    tok1d = torch.from_numpy(toks[0]).long()
+    with torch.no_grad():
+        out["sum/r71"] = t2n(mixin_bytes(et[tok1d][None], eb[byte_inputs].squeeze()).float())
+        sc = torch.tensor([0.75, 1.25])
+        out["sum/r71041"] = t2n(mixin_bytes(norm(et[tok1d][None]) * sc[-1], norm(eb[byte_inputs].squeeze()) * sc[-2]).float())
+        out["sum/noop"] = t2n(norm(et[tok1d][None]).float())
+        out["sum/byte_embs"] = t2n(norm(eb[pulled.view(-1)]).float())
+    np.savez_compressed(OUT / "bf16.npz", **out)
+    print("bf16:", len(out), "arrays")
+
+
 def main():
     dc = load_data_creation()
     gen_ttb_fixture()
@@ -487,6 +511,7 @@ def main():
     mm = load_mathblations()
     gen_mathblations(*mm)
     gen_grads(dc, load_train_gpt_defs(), load_run71_defs(), mm[0])
+    gen_bf16(dc, load_train_gpt_defs(), load_run71_defs())
     meta = dict(torch=torch.__version__, numpy=np.__version__, python=sys.version.split()[0],
                 threads=torch.get_num_threads(), reference="snimu/mixture-of-tokenizers @ 2025-08-24",
                 generator="oracle/gen_golden.py")

@@ -258,6 +258,11 @@ int oracle_rank_slice_shift(const int32_t *data, int64_t pos, int64_t batch,
 /* Float path, instantiated twice from mot_oracle_float.inc                 */
 /* ------------------------------------------------------------------------ */
 
+/* F.rms_norm(eps=None) takes eps from the INPUT dtype; to restate the bf16 path (tables held as
+ * bf16-representable floats) the tests set eps = torch.finfo(bfloat16).eps = 2^-7 here; 0 = per-type default. */
+static double g_eps_override = 0.0;
+void oracle_set_eps(double eps) { g_eps_override = eps; }
+
 /* mixing modes (values shared with nothing in the product on purpose) */
 #define O_MODE_NOOP 0          /* x = tok part only                                  */
 #define O_MODE_SUM 1           /* x = a + concat_k b_k   (runs/71*.py:227-230)       */

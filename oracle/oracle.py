@@ -50,6 +50,19 @@ def set_threads(n: int) -> None:
         pass
 
 
+def set_eps(eps: float) -> None:
+    """rms-norm eps override (0 restores the per-dtype default); 2**-7 restates the bf16 path."""
+    lib().oracle_set_eps(C.c_double(eps))
+
+
+def bf16_round(a) -> np.ndarray:
+    """Round float32/float64 values to the nearest bfloat16 (ties to even), returned as float32."""
+    x = np.ascontiguousarray(a, dtype=np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(x.shape)
+
+
 def _p(a, ct):
     return None if a is None else a.ctypes.data_as(C.POINTER(ct))
 

@@ -1,0 +1,86 @@
+"""-m gpu: bf16 tables / bf16 output (the dtype the reference's training loop runs: nn.Embedding ->
+bf16, train_gpt.py:1124-1126).  The kernels widen rows to fp32, compute in fp32 and round once on
+store; eps defaults to finfo(bfloat16).eps as F.rms_norm(eps=None) does on bf16 inputs.
+
+Bars: vs the float64 oracle evaluated on the same bf16-valued tables and rounded to bf16: within
+1 bf16 ulp (2^-8 relative); vs the reference's EAGER bf16 path (which rounds intermediates to bf16
+after every op): within 2 bf16 ulps."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import oracle as orc
+from util_gpu import DEV, dev, host
+
+pytestmark = pytest.mark.gpu
+G = gi.GOLDEN_DIR
+ULP = 2.0 ** -8
+
+
+def ulps(got, ref):
+    got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+    return np.abs(got - ref) / (ULP * np.maximum(np.abs(ref), 2.0 ** -6))
+
+
+@pytest.fixture(scope="module")
+def mot():
+    import mixture_of_tokenizers_amd as m
+    return m
+
+
+def bf(a):
+    return dev(orc.bf16_round(a)).to(torch.bfloat16)
+
+
+def test_bf16_vs_reference_eager(mot):
+    name, Vt, D, Db, bpt, T, seed = ("c2dims", 512, 768, 48, 16, 48, 502)
+    z = np.load(G / "bf16.npz")
+    toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+    tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+    Et, Eb = bf(gi.normal_table(seed + 1, Vt, D)), bf(gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db))
+    x = mot.embed_mix(dev(toks), Et, Eb, mode="sum", bpt=bpt, ttb=dev(tab), pull="left", norm_out=True)
+    assert x.dtype == torch.bfloat16 and x.shape == (1, T, D)
+    assert ulps(host(x.float()), z["sum/r71"]).max() <= 2
+    x = mot.embed_mix(dev(toks), Et, Eb, mode="sum", bpt=bpt, ttb=dev(tab), pull="left", norm_tok=True, norm_byte=True,
+                      norm_out=True, scale_tok=torch.tensor(1.25, device=DEV), scale_byte=torch.tensor(0.75, device=DEV))
+    assert ulps(host(x.float()), z["sum/r71041"]).max() <= 2
+    x = mot.embed_mix(dev(toks), Et, mode="noop", norm_tok=True)
+    assert ulps(host(x.float()), z["sum/noop"]).max() <= 1
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    be = mot.gather_rows(Eb, dev(pulled), rms_norm=True)
+    assert be.dtype == torch.bfloat16
+    assert ulps(host(be.float()).reshape(-1, Db), z["sum/byte_embs"]).max() <= 1
+
+
+@pytest.mark.parametrize("D,Db,bpt,Vt,B,T,kw,seed", [
+    (768, 48, 16, 50257, 4, 1024, dict(norm_out=True), 9501),
+    (256, 32, 8, 512, 3, 333, dict(norm_tok=True, norm_byte=True, norm_out=True), 9502),
+    (2048, 128, 16, 512, 2, 70, dict(), 9503),
+])
+def test_bf16_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left")
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = orc.bf16_round(gi.normal_table(seed + 2, Vt, D)), orc.bf16_round(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    orc.set_eps(2.0 ** -7)
+    try:
+        ref = orc.embed_mix(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), mode="sum", bpt=bpt, dtype=np.float64, **kw)
+    finally:
+        orc.set_eps(0.0)
+    r = mot.embed_mix(dev(toks), dev(Et).bfloat16(), dev(Eb).bfloat16(), mode="sum", bpt=bpt, ttb=dev(tab), pull="left",
+                      return_ids=True, **kw)
+    np.testing.assert_array_equal(host(r.ids_pulled), pulled)
+    assert ulps(host(r.x.float()), orc.bf16_round(ref)).max() <= 1
+    assert (host(r.x.float()) == orc.bf16_round(ref)).mean() > 0.98     # almost always the same rounding
+
+
+def test_bf16_limits(mot):
+    Et, Eb = torch.zeros(8, 64, device=DEV, dtype=torch.bfloat16), torch.zeros(458, 8, device=DEV)
+    toks = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
+    ids = torch.zeros((1, 32), dtype=torch.int64, device=DEV)
+    with pytest.raises(TypeError):      # mixed table dtypes
+        mot.embed_mix(toks, Et, Eb, mode="sum", bpt=8, ids_a=ids)
+    with pytest.raises(NotImplementedError, match="bf16 MFMA"):
+        mot.embed_mix(toks, Et, Eb.bfloat16(), mode="concat_linear", bpt=8, ids_a=ids,
+                      weight=torch.zeros(64, 128, device=DEV, dtype=torch.bfloat16))
