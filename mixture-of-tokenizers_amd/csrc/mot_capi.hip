@@ -76,8 +76,10 @@ static int validate_embed_mix(const MotEmbedMixDesc *d) {
             break;
     }
     if (d->mode != MOT_MIX_CONCAT_LINEAR) {
-        if ((d->tok_dim & 3) || (d->mode == MOT_MIX_SUM && (d->byte_dim & 3)))
-            return set_error(MOT_EUNSUPPORTED, "embed_mix: dims must be multiples of 4 floats (tok_dim %d, byte_dim %d)", d->tok_dim, d->byte_dim);
+        const int vec = d->dtype == MOT_BF16 ? 8 : 4;  // elements per 16-byte lane load
+        if ((d->tok_dim % vec) || (d->mode == MOT_MIX_SUM && (d->byte_dim % vec)))
+            return set_error(MOT_EUNSUPPORTED, "embed_mix: tok_dim %d / byte_dim %d must be multiples of %d elements (16 bytes)", d->tok_dim,
+                             d->byte_dim, vec);
         if (d->tok_dim > 2048) return set_error(MOT_EUNSUPPORTED, "embed_mix: model_dim %d > 2048 is not built", d->tok_dim);
         if (dual && d->norm_byte)
             return set_error(MOT_EUNSUPPORTED, "embed_mix: norm_byte over two id tensors is only built for CONCAT_LINEAR");

@@ -18,7 +18,7 @@ namespace mot {
 // ------------------------------------------------------------------------------------------ fused kernel
 // MODE: MOT_MIX_NOOP / SUM / MEAN.   NCH: float4 chunks per lane (covers Dm <= 256*NCH).
 // U: tokens in flight per wave.
-template <int MODE, int NCH, int U, typename T>
+template <int MODE, int NCH, int U, typename T, bool DUAL>
 __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
     const T *tok_table = (const T *)A.tok_table, *byte_table = (const T *)A.byte_table;
     extern __shared__ int32_t lds[];
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
     const int64_t t0 = (int64_t)(blockIdx.x % A.tiles_per_row) * A.tile_tokens;
     const int ntok = (int)min((int64_t)A.tile_tokens, A.T - t0);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool dual = has_ids && (A.id_source == MOT_IDS_FROM_TTB ? A.add_padded != 0 : A.ids_b != nullptr);
+    constexpr bool dual = DUAL;  // two id tensors: emb(padded) + emb(pulled)
 
     if (!has_ids) {
         if ((int)threadIdx.x < ntok) L.tok[threadIdx.x] = A.tokens[row * A.T + t0 + threadIdx.x];
@@ -43,8 +43,10 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
     }
 
     // ---- phase 2
+    typedef typename Elem<T>::vec vec_t;          // VEC floats: one 16-byte lane load (4 fp32 / 8 bf16)
+    constexpr int VEC = Elem<T>::kVec;
     const int sv = A.bpt | 1;
-    const int Dm = A.Dt, nchunk = Dm >> 2;
+    const int Dm = A.Dt, nchunk = Dm / VEC;
     int slot[NCH], within[NCH];
     bool act[NCH];
 #pragma unroll
@@ -53,20 +55,29 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
         act[i] = c < nchunk;
         const int cc = act[i] ? c : 0;
         if (MODE == MOT_MIX_SUM) {
-            slot[i] = (4 * cc) / A.Db;            // concat_k: column j belongs to slot j / Db
-            within[i] = 4 * cc - slot[i] * A.Db;
+            slot[i] = (VEC * cc) / A.Db;            // concat_k: column j belongs to slot j / Db
+            within[i] = VEC * cc - slot[i] * A.Db;
         } else {
             slot[i] = 0;
-            within[i] = 4 * cc;
+            within[i] = VEC * cc;
         }
     }
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     const bool scale_t = A.scale_tok != nullptr, scale_b = A.scale_byte != nullptr;
     T *orow = (T *)A.out + (row * A.T + t0) * (int64_t)Dm;
+    auto sumsq = [](const vec_t &v) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[e] * v[e];
+        return s;
+    };
 
+    typedef typename Elem<T>::raw raw_t;
     for (int tb = wave * U; tb < ntok; tb += kWaves * U) {
-        float4v a[U][NCH], b[U][NCH];
+        raw_t ar[U][NCH], br[U][NCH], br2[DUAL ? U : 1][NCH];  // rows exactly as loaded (bf16 stays packed until it is used)
+        vec_t bm[U][NCH];                           // MEAN accumulates while loading
+        int idr[U][NCH];
         // ---- issue every load of the U tokens before touching any of them
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -79,29 +90,25 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
             const T *trow = tok_table + (int64_t)tok * Dm;
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                a[u][i] = act[i] ? Elem<T>::load4(trow + 4 * (lane + 64 * i)) : (float4v)(0.f);
+                ar[u][i] = Elem<T>::load_raw(trow + VEC * (act[i] ? lane + 64 * i : 0));
                 if (MODE == MOT_MIX_SUM) {
                     const int id = L.ids[t * sv + slot[i]];
-                    float4v v = Elem<T>::load4(byte_table + (int64_t)id * A.Db + within[i]);
-                    if (dual) {  // norm(emb(padded) + emb(pulled)) without the norm (train_gpt.py:378)
-                        const int id2 = L.val[t * sv + slot[i]];
-                        v += Elem<T>::load4(byte_table + (int64_t)id2 * A.Db + within[i]);
-                    }
-                    if (A.norm_byte) v *= A.byte_rnorm[id];
-                    b[u][i] = v;
+                    idr[u][i] = id;
+                    br[u][i] = Elem<T>::load_raw(byte_table + (int64_t)id * A.Db + within[i]);
+                    if (dual) br2[DUAL ? u : 0][i] = Elem<T>::load_raw(byte_table + (int64_t)L.val[t * sv + slot[i]] * A.Db + within[i]);
                 } else if (MODE == MOT_MIX_MEAN) {
-                    float4v acc = (float4v)(0.f);
+                    vec_t acc = (vec_t)(0.f);
                     for (int k = 0; k < A.bpt; ++k) {  // chars.mean(dim=-2), inference.py:267
                         const int id = L.ids[t * sv + k];
-                        float4v v = Elem<T>::load4(byte_table + (int64_t)id * A.Db + within[i]);
+                        vec_t v = Elem<T>::loadv(byte_table + (int64_t)id * A.Db + within[i]);
                         if (dual) {
                             const int id2 = L.val[t * sv + k];
-                            v += Elem<T>::load4(byte_table + (int64_t)id2 * A.Db + within[i]);
+                            v += Elem<T>::loadv(byte_table + (int64_t)id2 * A.Db + within[i]);
                         }
                         if (A.norm_byte) v *= A.byte_rnorm[id];
                         acc += v;
                     }
-                    b[u][i] = acc / (float)A.bpt;
+                    bm[u][i] = acc / (float)A.bpt;
                 }
             }
         }
@@ -109,28 +116,41 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = tb + u;
+            vec_t a[1][NCH], b[1][NCH];
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                a[0][i] = act[i] ? Elem<T>::widen(ar[u][i]) : (vec_t)(0.f);
+                if (MODE == MOT_MIX_SUM) {
+                    vec_t v = Elem<T>::widen(br[u][i]);
+                    if (dual) v += Elem<T>::widen(br2[DUAL ? u : 0][i]);  // emb(padded) + emb(pulled), train_gpt.py:378
+                    if (A.norm_byte) v *= A.byte_rnorm[idr[u][i]];
+                    b[0][i] = v;
+                } else if (MODE == MOT_MIX_MEAN) {
+                    b[0][i] = bm[u][i];
+                }
+            }
             if (A.norm_tok) {
                 float ss = 0.f;
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) ss += a[u][i].x * a[u][i].x + a[u][i].y * a[u][i].y + a[u][i].z * a[u][i].z + a[u][i].w * a[u][i].w;
+                for (int i = 0; i < NCH; ++i) ss += sumsq(a[0][i]);
                 const float r = rms_scale(wave_sum(ss), Dm, A.eps);
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) a[u][i] *= r;
+                for (int i = 0; i < NCH; ++i) a[0][i] *= r;
             }
             if (scale_t) {
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) a[u][i] *= s_tok;
+                for (int i = 0; i < NCH; ++i) a[0][i] *= s_tok;
             }
-            float4v x[NCH];
+            vec_t x[NCH];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                if (MODE == MOT_MIX_NOOP) x[i] = a[u][i];
-                else x[i] = a[u][i] + (scale_b ? b[u][i] * s_byte : b[u][i]);
+                if (MODE == MOT_MIX_NOOP) x[i] = a[0][i];
+                else x[i] = a[0][i] + (scale_b ? b[0][i] * s_byte : b[0][i]);
             }
             if (A.norm_out) {
                 float ss = 0.f;
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) ss += act[i] ? x[i].x * x[i].x + x[i].y * x[i].y + x[i].z * x[i].z + x[i].w * x[i].w : 0.f;
+                for (int i = 0; i < NCH; ++i) ss += act[i] ? sumsq(x[i]) : 0.f;
                 const float r = rms_scale(wave_sum(ss), Dm, A.eps);
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) x[i] *= r;
@@ -138,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
             if (t < ntok) {
 #pragma unroll
                 for (int i = 0; i < NCH; ++i)
-                    if (act[i]) Elem<T>::store4_nt(orow + (int64_t)t * Dm + 4 * (lane + 64 * i), x[i]);
+                    if (act[i]) Elem<T>::storev_nt(orow + (int64_t)t * Dm + VEC * (lane + 64 * i), x[i]);
             }
         }
     }
@@ -275,26 +295,37 @@ size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d) {
     return 0;
 }
 
-template <int MODE, int NCH, int U>
-static int launch_mix(const MixArgs &A, int dtype, int64_t blocks, size_t lds, hipStream_t stream) {
-    if (dtype == MOT_BF16)
-        hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U, __bf16>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
+template <int MODE, int NCH, int U, typename T>
+static int launch_mix(const MixArgs &A, int64_t blocks, size_t lds, hipStream_t stream) {
+    const bool dual = MODE != MOT_MIX_NOOP && (A.id_source == MOT_IDS_FROM_TTB ? A.add_padded != 0 : A.ids_b != nullptr);
+    if (dual)
+        hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U, T, true>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
     else
-        hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U, float>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
+        hipLaunchKernelGGL((embed_mix_kernel<MODE, NCH, U, T, false>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A);
     return check_launch("embed_mix_kernel");
 }
 
+// NCH = 16-byte chunks per lane: ceil(D / (64 * VEC)).  U keeps ~12 independent 16 B loads per lane in flight.
 template <int MODE>
-static int dispatch_nch(const MixArgs &A, int dtype, int nch, int64_t blocks, size_t lds, hipStream_t stream) {
-    switch (nch) {
-        case 1: return launch_mix<MODE, 1, 4>(A, dtype, blocks, lds, stream);
-        case 2: return launch_mix<MODE, 2, 4>(A, dtype, blocks, lds, stream);
-        case 3: return launch_mix<MODE, 3, 2>(A, dtype, blocks, lds, stream);
-        case 4: return launch_mix<MODE, 4, 2>(A, dtype, blocks, lds, stream);
+static int dispatch_nch(const MixArgs &A, int dtype, int64_t blocks, size_t lds, hipStream_t stream) {
+    if (dtype == MOT_BF16) {
+        switch ((A.Dt / 8 + 63) / 64) {
+            case 1: return launch_mix<MODE, 1, 4, __bf16>(A, blocks, lds, stream);
+            case 2: return launch_mix<MODE, 2, 4, __bf16>(A, blocks, lds, stream);
+            case 3: return launch_mix<MODE, 3, 2, __bf16>(A, blocks, lds, stream);
+            case 4: return launch_mix<MODE, 4, 2, __bf16>(A, blocks, lds, stream);
+            default: return set_error(MOT_EUNSUPPORTED, "embed_mix: model_dim %d > 2048 is not built", A.Dt);
+        }
+    }
+    switch ((A.Dt / 4 + 63) / 64) {
+        case 1: return launch_mix<MODE, 1, 4, float>(A, blocks, lds, stream);
+        case 2: return launch_mix<MODE, 2, 4, float>(A, blocks, lds, stream);
+        case 3: return launch_mix<MODE, 3, 2, float>(A, blocks, lds, stream);
+        case 4: return launch_mix<MODE, 4, 2, float>(A, blocks, lds, stream);
         case 5:
-        case 6: return launch_mix<MODE, 6, 1>(A, dtype, blocks, lds, stream);
+        case 6: return launch_mix<MODE, 6, 1, float>(A, blocks, lds, stream);
         case 7:
-        case 8: return launch_mix<MODE, 8, 1>(A, dtype, blocks, lds, stream);
+        case 8: return launch_mix<MODE, 8, 1, float>(A, blocks, lds, stream);
         default: return set_error(MOT_EUNSUPPORTED, "embed_mix: model_dim %d > 2048 is not built", A.Dt);
     }
 }
@@ -320,11 +351,10 @@ int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
         if (rc) return rc;
         A.byte_rnorm = rn;
     }
-    const int nch = (d.tok_dim / 4 + 63) / 64;
     switch (d.mode) {
-        case MOT_MIX_NOOP: return dispatch_nch<MOT_MIX_NOOP>(A, d.dtype, nch, blocks, lds, stream);
-        case MOT_MIX_SUM: return dispatch_nch<MOT_MIX_SUM>(A, d.dtype, nch, blocks, lds, stream);
-        case MOT_MIX_MEAN: return dispatch_nch<MOT_MIX_MEAN>(A, d.dtype, nch, blocks, lds, stream);
+        case MOT_MIX_NOOP: return dispatch_nch<MOT_MIX_NOOP>(A, d.dtype, blocks, lds, stream);
+        case MOT_MIX_SUM: return dispatch_nch<MOT_MIX_SUM>(A, d.dtype, blocks, lds, stream);
+        case MOT_MIX_MEAN: return dispatch_nch<MOT_MIX_MEAN>(A, d.dtype, blocks, lds, stream);
         default: return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d.mode);
     }
 }

@@ -10,18 +10,34 @@
 namespace mot {
 
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
 
 // Element access for the two table/output formats.  All arithmetic is fp32; bf16 rows are widened on
 // load (8 B per lane-chunk) and results rounded once, to nearest-even, on store (v_cvt_pk_bf16_f32).
 template <typename T> struct Elem;
 template <> struct Elem<float> {
+    typedef float4v vec;               // one 16-byte lane load
+    typedef float4v raw;               // as it sits in registers while the load is in flight
+    static constexpr int kVec = 4;
+    static __device__ __forceinline__ raw load_raw(const float *p) { return *(const float4v *)p; }
+    static __device__ __forceinline__ vec widen(raw r) { return r; }
+    static __device__ __forceinline__ float4v loadv(const float *p) { return *(const float4v *)p; }
+    static __device__ __forceinline__ void storev_nt(float *p, float4v v) { __builtin_nontemporal_store(v, (float4v *)p); }
     static __device__ __forceinline__ float4v load4(const float *p) { return *(const float4v *)p; }
     static __device__ __forceinline__ float load1(const float *p) { return *p; }
     static __device__ __forceinline__ void store4_nt(float *p, float4v v) { __builtin_nontemporal_store(v, (float4v *)p); }
     static __device__ __forceinline__ void store1(float *p, float v) { *p = v; }
 };
 template <> struct Elem<__bf16> {
+    typedef float8v vec;
+    typedef bf16x8v raw;               // 4 VGPRs in flight instead of 8: twice the tokens per wave
+    static constexpr int kVec = 8;
+    static __device__ __forceinline__ raw load_raw(const __bf16 *p) { return *(const bf16x8v *)p; }
+    static __device__ __forceinline__ vec widen(raw r) { return __builtin_convertvector(r, float8v); }
+    static __device__ __forceinline__ float8v loadv(const __bf16 *p) { return __builtin_convertvector(*(const bf16x8v *)p, float8v); }
+    static __device__ __forceinline__ void storev_nt(__bf16 *p, float8v v) { __builtin_nontemporal_store(__builtin_convertvector(v, bf16x8v), (bf16x8v *)p); }
     static __device__ __forceinline__ float4v load4(const __bf16 *p) { return __builtin_convertvector(*(const bf16x4v *)p, float4v); }
     static __device__ __forceinline__ float load1(const __bf16 *p) { return (float)*p; }
     static __device__ __forceinline__ void store4_nt(__bf16 *p, float4v v) { __builtin_nontemporal_store(__builtin_convertvector(v, bf16x4v), (bf16x4v *)p); }
