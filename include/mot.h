@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 3
+#define MOT_ABI_VERSION 4
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -187,6 +187,8 @@ typedef struct MotEmbedMixDesc {
     int64_t *counters;       /* optional int64[4], atomically incremented: tokens, byte slots,
                                 pads before the pull, pads after (runs/79_*.py:484-488)        */
     uint32_t *status;        /* optional device word, see MOT_STATUS_* */
+    float *out_row_rnorm;    /* optional [B, T] fp32: rsqrt(mean(y^2)+eps) of every output row when norm_out
+                                (CONCAT_LINEAR); saved by autograd so the backward need not redo the GEMM */
 
     /* scratch */
     void *workspace; /* >= mot_embed_mix_workspace_bytes(desc); may be NULL when that is 0 */
@@ -199,7 +201,9 @@ typedef struct MotEmbedMixDesc {
  * `fwd` is the forward's descriptor with id_source == MOT_IDS_GIVEN (pass the byte ids the forward
  * returned through out_ids_*); `out`, `out_ids_*`, `counters` are ignored.  Gradients are ACCUMULATED
  * (+=) into the given buffers, so a parameter's .grad can be passed directly; NULL = not wanted.
- * Built this round: MOT_MIX_SUM and MOT_MIX_NOOP (others return MOT_EUNSUPPORTED).
+ * Built: MOT_MIX_SUM, MOT_MIX_NOOP and MOT_MIX_CONCAT_LINEAR (fp32; MEAN returns MOT_EUNSUPPORTED).
+ * CONCAT_LINEAR additionally needs `out` (the forward's x) and, when norm_out, `out_row_rnorm` of the
+ * forward in `fwd`, and a workspace of mot_embed_mix_bwd_workspace_bytes(fwd).
  * Sums use float atomics: results are order-dependent in the last bits, like the reference's own
  * GPU embedding backward.
  */
@@ -209,8 +213,8 @@ typedef struct MotEmbedMixGrads {
     const void *grad_out;  /* [B, T, model_dim] upstream gradient dL/dx */
     void *d_tok_table;     /* [tok_rows, tok_dim]   */
     void *d_byte_table;    /* [byte_rows, byte_dim] */
-    void *d_weight;        /* [model_dim, K]   (CONCAT_LINEAR, not built yet) */
-    void *d_bias;          /* [model_dim]      (CONCAT_LINEAR, not built yet) */
+    void *d_weight;        /* [model_dim, K]   (CONCAT_LINEAR) */
+    void *d_bias;          /* [model_dim]      (CONCAT_LINEAR with bias; optional) */
     float *d_scale_tok;    /* scalar */
     float *d_scale_byte;   /* scalar */
 } MotEmbedMixGrads;

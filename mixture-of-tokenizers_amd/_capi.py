@@ -23,7 +23,7 @@ MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32, BF16 = 0, 1
 MAX_BPT = 64
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def dtype_code(t: torch.dtype) -> int:
@@ -55,7 +55,7 @@ class MotEmbedMixDesc(C.Structure):
         ("norm_tok", C.c_int32), ("norm_byte", C.c_int32), ("norm_out", C.c_int32), ("eps", C.c_float),
         ("scale_tok", C.c_void_p), ("scale_byte", C.c_void_p),
         ("out", C.c_void_p), ("out_ids_padded", C.c_void_p), ("out_ids_pulled", C.c_void_p),
-        ("counters", C.c_void_p), ("status", C.c_void_p),
+        ("counters", C.c_void_p), ("status", C.c_void_p), ("out_row_rnorm", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 

@@ -24,6 +24,7 @@
 // Float atomics make the sums order-dependent in the last bits, like the reference's own GPU
 // embedding backward; the parity tests state the tolerance they use against a float64 evaluation.
 #include <stdlib.h>
+#include <string.h>
 
 #include "mot_mix.hpp"
 
@@ -51,6 +52,9 @@ struct BwdArgs {
     const float *grad_out;
     float *d_tok, *d_byte, *d_scale_tok, *d_scale_byte;
     uint32_t *status;
+    // layout of one gradient row of D elements: token part [tok_lo, tok_lo+Dt), byte part [byte_lo, byte_lo+bpt*Db).
+    // SUM: both parts span the whole row (x = a + concat b); CONCAT_LINEAR: they are the two halves of du = dy.W
+    int Dt, tok_lo, byte_lo, nbk;
     int privatize;  // byte-table gradient accumulated in LDS
     const int32_t *pos_sorted;  // token positions ordered by token id
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
@@ -67,9 +71,12 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
     __syncthreads();
 
     const int D = A.D;
-    const float inv_db = MODE == MOT_MIX_SUM ? 1.0f / (float)A.Db : 0.f;
+    const float inv_db = MODE != MOT_MIX_NOOP ? 1.0f / (float)A.Db : 0.f;
     // element e = lane + 64*j of a row lives in byte slot e / Db; (e + 0.5) * (1/Db) floors exactly for e < 2048
-    auto slot_of = [&](int e) { return MODE == MOT_MIX_SUM ? __float2int_rd(((float)e + 0.5f) * inv_db) : 0; };
+    auto slot_of = [&](int eb) { return MODE != MOT_MIX_NOOP ? __float2int_rd(((float)eb + 0.5f) * inv_db) : 0; };
+    const int Dt = A.Dt;
+    auto tok_off = [&](int e) { const int o = e - A.tok_lo; return (e < D && (unsigned)o < (unsigned)Dt) ? o : -1; };
+    auto byte_off = [&](int e) { const int o = e - A.byte_lo; return (MODE != MOT_MIX_NOOP && e < D && (unsigned)o < (unsigned)A.nbk) ? o : -1; };
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     float ds_t = 0.f, ds_b = 0.f;
@@ -78,10 +85,12 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
     int cur = -1;
     auto flush = [&]() {
         if (cur < 0 || (A.abl & 2)) return;
-        float *drow = A.d_tok + (int64_t)cur * D;
+        float *drow = A.d_tok + (int64_t)cur * Dt;
 #pragma unroll
-        for (int j = 0; j < NE; ++j)
-            if (lane + 64 * j < D) atomicAdd(drow + lane + 64 * j, acc[j]);
+        for (int j = 0; j < NE; ++j) {
+            const int o = tok_off(lane + 64 * j);
+            if (o >= 0) atomicAdd(drow + o, acc[j]);
+        }
     };
     // Each position needs position -> token -> rows and position -> byte ids -> byte rows: up to four
     // dependent round trips.  The index side (position, token, byte ids) of position i+1 is therefore
@@ -90,9 +99,9 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             ids[j] = 0;
-            const int e = lane + 64 * j;
-            if (MODE == MOT_MIX_SUM && e < D) {
-                int64_t ia = A.ids_a[n * A.bpt + slot_of(e)];
+            const int eb = byte_off(lane + 64 * j);
+            if (eb >= 0) {
+                int64_t ia = A.ids_a[n * A.bpt + slot_of(eb)];
                 if ((uint64_t)ia >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); ia = 0; }
                 ids[j] = (int)ia;
             }
@@ -128,19 +137,19 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
 #pragma unroll
             for (int j = 0; j < NE; ++j) acc[j] = 0.f;
         }
-        const float *trow = A.tok_table + (int64_t)tok * D;
+        const float *trow = A.tok_table + (int64_t)tok * Dt;
         const float *grow = A.grad_out + n * D;
         float an[NE], bn[NE], dy[NE];
         // ---- gather (the same rows the forward read)
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int e = lane + 64 * j;
-            const bool act = e < D;
-            an[j] = act ? trow[e] : 0.f;
-            dy[j] = act ? grow[e] : 0.f;  // holds g until the norm backward below
+            const int et = tok_off(e), eb = byte_off(e);
+            an[j] = et >= 0 ? trow[et] : 0.f;
+            dy[j] = e < D ? grow[e] : 0.f;  // holds g until the norm backward below
             bn[j] = 0.f;
-            if (MODE == MOT_MIX_SUM && act) {
-                const int sl = slot_of(e), wi = e - sl * A.Db;
+            if (eb >= 0) {
+                const int sl = slot_of(eb), wi = eb - sl * A.Db;
                 float v = A.byte_table[(int64_t)id1[j] * A.Db + wi];
                 if (A.ids_b) {
                     int64_t ib = A.ids_b[n * A.bpt + sl];
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
             float ss = 0.f;
 #pragma unroll
             for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
-            ra = rms_scale(wave_sum(ss), D, A.eps);
+            ra = rms_scale(wave_sum(ss), Dt, A.eps);
 #pragma unroll
             for (int j = 0; j < NE; ++j) an[j] *= ra;
         }
@@ -188,7 +197,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
             for (int j = 0; j < NE; ++j) dot += dy[j] * an[j];
             ds_t += dot;  // d scale_tok = sum dy * a_n
             float mt = 0.f;
-            if (A.norm_tok) mt = wave_sum(dot * s_tok) / (float)D;
+            if (A.norm_tok) mt = wave_sum(dot * s_tok) / (float)Dt;
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const float da = dy[j] * s_tok;
@@ -196,7 +205,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
             }
         }
         // ---- byte side
-        if (MODE == MOT_MIX_SUM) {
+        if (MODE != MOT_MIX_NOOP) {
             float dot = 0.f;
 #pragma unroll
             for (int j = 0; j < NE; ++j) dot += dy[j] * bn[j];
@@ -205,15 +214,17 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
                 if (lane < A.bpt) seg[lane] = 0.f;
                 __threadfence_block();
 #pragma unroll
-                for (int j = 0; j < NE; ++j)
-                    if (lane + 64 * j < D) atomicAdd(&seg[slot_of(lane + 64 * j)], dy[j] * s_byte * bn[j]);
+                for (int j = 0; j < NE; ++j) {
+                    const int eb = byte_off(lane + 64 * j);
+                    if (eb >= 0) atomicAdd(&seg[slot_of(eb)], dy[j] * s_byte * bn[j]);
+                }
                 __threadfence_block();
             }
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
-                const int e = lane + 64 * j;
-                if (e >= D) continue;
-                const int sl = slot_of(e), wi = e - sl * A.Db;
+                const int eb = byte_off(lane + 64 * j);
+                if (eb < 0) continue;
+                const int sl = slot_of(eb), wi = eb - sl * A.Db;
                 const float db = dy[j] * s_byte;
                 float v = db;
                 if (A.norm_byte) v = A.byte_rnorm[id1[j]] * (db - bn[j] * (seg[sl] / (float)A.Db));
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
     // ---- flush
     flush();
     if (A.d_scale_tok) { ds_t = wave_sum(ds_t); if (lane == 0) atomicAdd(A.d_scale_tok, ds_t); }
-    if (MODE == MOT_MIX_SUM && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
+    if (MODE != MOT_MIX_NOOP && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
     if (A.privatize) {
         __syncthreads();
         for (int i = tid; i < nbyte; i += kBwdThreads) {
@@ -310,18 +321,46 @@ static int dispatch_ne(const BwdArgs &A, size_t lds, hipStream_t stream) {
     return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: model_dim %d > 2048 is not built", A.D);
 }
 
-// workspace: [byte_rnorm: byte_rows f32][counts: tok_rows][cursor: tok_rows][starts: tok_rows][pos_sorted: N] (int32)
-static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
-size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
-    return (bwd_rnorm_floats(d) + 3 * (size_t)d.tok_rows + (size_t)(d.n_rows * d.tokens_per_row)) * 4;
+// ------------------------------------------------------------------------------------------
+// scatter stage shared by all modes: sort the positions by token id, then embed_mix_bwd_kernel.
+// `ws_ints` = [counts: tok_rows][cursor: tok_rows][starts: tok_rows][pos_sorted: N] (int32).
+// ------------------------------------------------------------------------------------------
+static size_t scatter_ws_ints(const MotEmbedMixDesc &d) { return 3 * (size_t)d.tok_rows + (size_t)(d.n_rows * d.tokens_per_row); }
+
+template <int MODE>
+static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, float *rnorm_ws, hipStream_t stream) {
+    int32_t *counts = ws_ints, *cursor = counts + d.tok_rows, *starts = cursor + d.tok_rows, *pos_sorted = starts + d.tok_rows;
+    hipError_t e = hipMemsetAsync(counts, 0, 2 * (size_t)d.tok_rows * sizeof(int32_t), stream);  // counts + cursor
+    if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+    int64_t hb = (A.n_tokens + kThreads - 1) / kThreads;
+    if (hb > 2048) hb = 2048;
+    hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts);
+    hipLaunchKernelGGL(bwd_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, A.tok_rows, starts);
+    hipLaunchKernelGGL(bwd_scatter_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows,
+                       starts, cursor, pos_sorted);
+    int rc = check_launch("embed_mix_bwd sort kernels");
+    if (rc) return rc;
+    A.pos_sorted = pos_sorted;
+    A.abl = 0;
+#ifdef MOT_DEV_ABLATION
+    if (getenv("MOT_BWD_ABL")) A.abl = atoi(getenv("MOT_BWD_ABL"));
+    if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
+#endif
+    size_t lds = (size_t)kBwdWaves * kMaxBpt * sizeof(float);
+    A.privatize = 0;
+    if (MODE != MOT_MIX_NOOP) {
+        const size_t tab = (size_t)d.byte_rows * d.byte_dim * sizeof(float);
+        if (tab + lds <= 150 * 1024) { A.privatize = 1; lds += tab; }
+        if (d.norm_byte) {
+            rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rnorm_ws, MOT_F32, stream);
+            if (rc) return rc;
+            A.byte_rnorm = rnorm_ws;
+        }
+    }
+    return dispatch_ne<MODE>(A, lds, stream);
 }
 
-int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream) {
-    if (d.mode != MOT_MIX_SUM && d.mode != MOT_MIX_NOOP)
-        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: only the SUM and NOOP modes are built (mode %d)", d.mode);
-    if (d.mode == MOT_MIX_SUM && d.id_source != MOT_IDS_GIVEN)
-        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
-    BwdArgs A;
+static void fill_bwd_args(BwdArgs &A, const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr) {
     A.tokens = d.tokens; A.n_tokens = d.n_rows * d.tokens_per_row; A.bpt = d.bpt;
     A.ids_a = d.ids_a; A.ids_b = d.ids_b;
     A.tok_table = (const float *)d.tok_table; A.tok_rows = d.tok_rows; A.D = d.tok_dim;
@@ -333,44 +372,247 @@ int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, h
     A.d_tok = (float *)gr.d_tok_table; A.d_byte = (float *)gr.d_byte_table;
     A.d_scale_tok = gr.d_scale_tok; A.d_scale_byte = gr.d_scale_byte;
     A.status = d.status;
-    if (A.n_tokens > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: more than 2^31 tokens");
+    A.Dt = d.tok_dim; A.tok_lo = 0; A.byte_lo = 0; A.nbk = d.bpt * d.byte_dim;
+}
+
+// ==========================================================================================
+// CONCAT_LINEAR backward:  x = rms_norm?(y), y = W u + bias, u = cat(a, b_*)
+//   dy = r_y (g - x mean(g x))                      dy_kernel (one wave per row)
+//   du = dy . W          (N x Dm) @ (Dm x K)        the forward MFMA kernel with dy as dense "token rows";
+//                                                   W in nn.Linear layout IS the k-major operand it wants
+//   dW += dy^T . u       (Dm x N) @ (N x K)         gemm_tn_kernel: split over tokens, fp32 MFMA, atomic accumulate;
+//                                                   u = the seam tensors (gather_rows with the norms/scales applied)
+//   dbias += colsum(dy)                             colsum_kernel
+//   table gradients: the scatter stage above on du (row layout = the concat layout)
+// ==========================================================================================
+__global__ __launch_bounds__(kThreads) void dy_kernel(const float *__restrict__ g, const float *__restrict__ x,
+                                                      const float *__restrict__ rnorm, int64_t n, int Dm, float *__restrict__ dy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const float *gr = g + r * Dm, *xr = x + r * Dm;
+    float m = 0.f;
+    for (int j = lane; j < Dm; j += 64) m += gr[j] * xr[j];
+    m = wave_sum(m) / (float)Dm;
+    const float ry = rnorm[r];
+    for (int j = lane; j < Dm; j += 64) dy[r * Dm + j] = ry * (gr[j] - xr[j] * m);
+}
+
+__global__ __launch_bounds__(kThreads) void colsum_kernel(const float *__restrict__ a, int64_t n, int cols, float *__restrict__ out) {
+    // each workgroup sums a strip of rows for every column, then one atomic per column
+    const int64_t rows_per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * rows_per, hi = min(n, lo + rows_per);
+    for (int c = threadIdx.x; c < cols; c += kThreads) {
+        float s = 0.f;
+        for (int64_t r = lo; r < hi; ++r) s += a[r * cols + c];
+        if (lo < hi) atomicAdd(out + c, s);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void iota_kernel(int32_t *p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) p[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(kThreads) void pad_copy_kernel(const float *__restrict__ src, int rows, int cols, float *__restrict__ dst,
+                                                            int rows_pad, int cols_pad) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < (int64_t)rows_pad * cols_pad; i += (int64_t)gridDim.x * kThreads) {
+        const int r = (int)(i / cols_pad), c = (int)(i - (int64_t)r * cols_pad);
+        dst[i] = (r < rows && c < cols) ? src[(int64_t)r * cols + c] : 0.f;
+    }
+}
+
+// C[j][k] += sum_n A[n][j] * B[n][k]   (A: n x M, B: n x Nc, C: M x Nc with leading dimension ldc), fp32 MFMA.
+// Workgroup = 128 x 128 output block (4 waves as 2 x 2, each 64 x 64 = 2 x 2 tiles of 32 x 32) over one
+// slice of the rows; 16 rows per step, double-buffered LDS, rows ARE the MFMA k index so both operands are
+// staged in their natural row-major layout.  Partial blocks are accumulated with float atomics
+// (128-byte contiguous segments per instruction).
+typedef float f32x16b __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const float *__restrict__ A_, int lda, int M, const float *__restrict__ B_, int ldb,
+                                                           int Nc, int64_t n, int64_t rows_per_split, float *__restrict__ C, int ldc) {
+    __shared__ __attribute__((aligned(16))) float lA[2][16 * 128], lB[2][16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
+    const int j0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int64_t r0 = (int64_t)blockIdx.z * rows_per_split, r1 = min(n, r0 + rows_per_split);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // staging role: 16 rows x 32 float4 per operand = 512 float4 -> 2 per thread
+    float4v ra[2], rb[2];
+    auto load_stage = [&](int64_t r) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + tid, row = q >> 5, c4 = (q & 31) * 4;
+            const int64_t rr = r + row;
+            ra[p] = (float4v)(0.f); rb[p] = (float4v)(0.f);
+            if (rr < r1) {
+                const float *pa = A_ + rr * lda + j0 + c4, *pb = B_ + rr * ldb + k0 + c4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {   // element-wise guards keep ragged right edges correct
+                    if (j0 + c4 + e < M) ra[p][e] = pa[e];
+                    if (k0 + c4 + e < Nc) rb[p][e] = pb[e];
+                }
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + tid;
+            *(float4v *)(&lA[buf][q * 4]) = ra[p];
+            *(float4v *)(&lB[buf][q * 4]) = rb[p];
+        }
+    };
+    load_stage(r0);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t r = r0; r < r1; r += 16, buf ^= 1) {
+        const bool more = r + 16 < r1;
+        if (more) load_stage(r + 16);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float a0 = lA[buf][(kk + h) * 128 + wm + li], a1 = lA[buf][(kk + h) * 128 + wm + 32 + li];
+            const float b0 = lB[buf][(kk + h) * 128 + wn + li], b1 = lB[buf][(kk + h) * 128 + wn + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5); A is the "row" (j) operand
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = j0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = k0 + wn + b * 32 + li;
+                if (j < M && k < Nc) atomicAdd(C + (int64_t)j * ldc + k, acc[a][b][r]);
+            }
+}
+
+static int launch_gemm_tn(const float *A_, int lda, int M, const float *B_, int ldb, int Nc, int64_t n, float *C, int ldc, hipStream_t stream) {
+    if (M <= 0 || Nc <= 0 || n <= 0) return MOT_OK;
+    const int gx = (M + 127) / 128, gy = (Nc + 127) / 128;
+    int64_t splits = (1024 + gx * gy - 1) / (gx * gy);                  // ~1024 workgroups in total
+    int64_t rows_per = ((n + splits - 1) / splits + 15) / 16 * 16;     // whole 16-row steps
+    if (rows_per < 256) rows_per = 256;
+    splits = (n + rows_per - 1) / rows_per;
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits), dim3(kThreads), 0, stream, A_, lda, M, B_, ldb,
+                       Nc, n, rows_per, C, ldc);
+    return check_launch("gemm_tn_kernel");
+}
+
+// workspace of the CONCAT backward, in floats unless noted:
+//   [rnorm: byte_rows][dy: N*Dm][du: N*K][u_tok: N*Dt][u_byte: N*bpt*Db][Wk: Dm16*K128][byte0: 4][iota: N int32][zero ids: 0]
+//   [sort ints: 3*tok_rows + N]
+struct LinBwdLayout { size_t rnorm, dy, du, utok, ubyte, wk, byte0, iota, sort, total; int Kp, Dmp; };
+static LinBwdLayout lin_bwd_layout(const MotEmbedMixDesc &d) {
+    LinBwdLayout L;
+    const size_t N = (size_t)(d.n_rows * d.tokens_per_row), K = (size_t)d.tok_dim + (size_t)d.bpt * d.byte_dim;
+    L.Kp = (int)((K + 127) / 128 * 128);            // output columns of the du GEMM, padded as the MFMA kernel pads them
+    if (L.Kp > 512 && L.Kp <= 768) L.Kp = 768; else if (L.Kp > 768) L.Kp = 1024;
+    L.Dmp = (d.model_dim + 15) / 16 * 16;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
+    L.rnorm = take(d.byte_rows); L.dy = take(N * d.model_dim); L.du = take(N * K); L.utok = take(N * d.tok_dim);
+    L.ubyte = take(N * d.bpt * d.byte_dim); L.wk = take((size_t)L.Dmp * L.Kp); L.byte0 = take(4); L.iota = take(N);
+    L.sort = take(scatter_ws_ints(d)); L.total = o;
+    return L;
+}
+
+static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
+size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
+    if (d.mode == MOT_MIX_CONCAT_LINEAR) {
+        // the du GEMM runs through launch_embed_mix_linear_ex with its own (small) scratch after ours
+        return lin_bwd_layout(d).total * 4 + 64;
+    }
+    return (bwd_rnorm_floats(d) + scatter_ws_ints(d)) * 4;
+}
+
+static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream) {
+    if (d.id_source != MOT_IDS_GIVEN) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
+    if (!gr.d_weight) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: d_weight missing");
+    if (d.norm_out && (!d.out || !d.out_row_rnorm)) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: needs the forward's out and out_row_rnorm");
+    const int64_t N = d.n_rows * d.tokens_per_row;
+    const int Dm = d.model_dim, Dt = d.tok_dim, nbk = d.bpt * d.byte_dim, K = Dt + nbk;
+    if (K > 1024 || Dm > 2048) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 or model_dim %d > 2048", K, Dm);
+    if (d.ids_b && d.norm_byte) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: norm over two id tensors is forward-only so far");
+    const LinBwdLayout L = lin_bwd_layout(d);
+    if (!d.workspace || d.workspace_bytes < L.total * 4)
+        return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
+    float *ws = (float *)d.workspace;
+    float *rn = ws + L.rnorm, *dy = ws + L.dy, *du = ws + L.du, *utok = ws + L.utok, *ubyte = ws + L.ubyte, *wk = ws + L.wk, *byte0 = ws + L.byte0;
+    int32_t *iota = (int32_t *)(ws + L.iota), *sort_ints = (int32_t *)(ws + L.sort);
+    const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    int rc;
+    // 1. dy
+    const float *dyp = (const float *)gr.grad_out;
+    if (d.norm_out) {
+        hipLaunchKernelGGL(dy_kernel, dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)gr.grad_out,
+                           (const float *)d.out, d.out_row_rnorm, N, Dm, dy);
+        if ((rc = check_launch("dy_kernel"))) return rc;
+        dyp = dy;
+    }
+    if (gr.d_bias) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(256), dim3(kThreads), 0, stream, dyp, N, Dm, (float *)gr.d_bias);
+        if ((rc = check_launch("colsum_kernel"))) return rc;
+    }
+    // 2. u = the seam tensors (norms and scalars applied), and dW += dy^T u
+    const int64_t blk = 2048;
+    (void)blk;
+    if ((rc = launch_gather_rows(d.tokens, nullptr, 4, N, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, d.scale_tok, utok, d.status, MOT_F32, stream))) return rc;
+    if ((rc = launch_gather_rows(d.ids_a, d.ids_b, 8, N * d.bpt, d.byte_table, d.byte_rows, d.byte_dim, d.norm_byte, eps, d.scale_byte, ubyte, d.status,
+                                 MOT_F32, stream))) return rc;
+    const int tok_lo = d.bytes_first ? nbk : 0, byte_lo = d.bytes_first ? 0 : Dt;
+    float *dW = (float *)gr.d_weight;
+    if ((rc = launch_gemm_tn(dyp, Dm, Dm, utok, Dt, Dt, N, dW + tok_lo, K, stream))) return rc;
+    if ((rc = launch_gemm_tn(dyp, Dm, Dm, ubyte, nbk, nbk, N, dW + byte_lo, K, stream))) return rc;
+    // 3. du = dy . W through the forward MFMA kernel: "token rows" = dy (ids 0..N-1), no byte part, weight operand = W itself
+    hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(kThreads), 0, stream, iota, N);
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(512), dim3(kThreads), 0, stream, (const float *)d.weight, Dm, K, wk, L.Dmp, L.Kp);
+    hipError_t e = hipMemsetAsync(byte0, 0, 16, stream);
+    if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+    if ((rc = check_launch("iota/pad_copy"))) return rc;
+    MotEmbedMixDesc g2;
+    memset(&g2, 0, sizeof(g2));
+    g2.struct_size = sizeof(g2); g2.dtype = MOT_F32;
+    g2.n_rows = 1; g2.tokens_per_row = N; g2.bpt = 0; g2.mode = MOT_MIX_CONCAT_LINEAR;
+    g2.tokens = iota; g2.id_source = MOT_IDS_GIVEN; g2.ids_a = (const int64_t *)iota;  // never read with bpt == 0
+    g2.tok_table = dyp; g2.tok_rows = N; g2.tok_dim = Dm; g2.byte_table = byte0; g2.byte_rows = 1; g2.byte_dim = 4;
+    g2.model_dim = K; g2.out = du; g2.status = d.status;
+    if ((rc = launch_embed_mix_linear_ex(g2, wk, L.Kp, stream))) return rc;
+    // 4. table gradients from du (its row layout is the concat layout)
+    BwdArgs A;
+    fill_bwd_args(A, d, gr);
+    A.grad_out = du; A.D = K; A.norm_out = 0;
+    A.Dt = Dt; A.tok_lo = tok_lo; A.byte_lo = byte_lo; A.nbk = nbk;
+    return run_scatter<MOT_MIX_CONCAT_LINEAR>(A, d, sort_ints, rn, stream);
+}
+
+int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream) {
+    if (d.n_rows * d.tokens_per_row > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: more than 2^31 tokens");
+    if (d.mode == MOT_MIX_CONCAT_LINEAR) return launch_embed_mix_bwd_linear(d, gr, stream);
+    if (d.mode != MOT_MIX_SUM && d.mode != MOT_MIX_NOOP)
+        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: the MEAN mode is forward-only (mode %d)", d.mode);
+    if (d.mode == MOT_MIX_SUM && d.id_source != MOT_IDS_GIVEN)
+        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
+    if (d.ids_b && d.norm_byte) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: norm over two id tensors is not built");
+    BwdArgs A;
+    fill_bwd_args(A, d, gr);
     const size_t need = embed_mix_bwd_workspace_bytes(d);
     if (!d.workspace || d.workspace_bytes < need)
         return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
     float *rn = (float *)d.workspace;
-    int32_t *counts = (int32_t *)(rn + bwd_rnorm_floats(d)), *cursor = counts + d.tok_rows, *starts = cursor + d.tok_rows;
-    int32_t *pos_sorted = starts + d.tok_rows;
-    {
-        hipError_t e = hipMemsetAsync(counts, 0, 2 * (size_t)d.tok_rows * sizeof(int32_t), stream);  // counts + cursor
-        if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-        int64_t hb = (A.n_tokens + kThreads - 1) / kThreads;
-        if (hb > 2048) hb = 2048;
-        hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts);
-        hipLaunchKernelGGL(bwd_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, A.tok_rows, starts);
-        hipLaunchKernelGGL(bwd_scatter_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows,
-                           starts, cursor, pos_sorted);
-        int rc = check_launch("embed_mix_bwd sort kernels");
-        if (rc) return rc;
-    }
-    A.pos_sorted = pos_sorted;
-    A.abl = 0;
-#ifdef MOT_DEV_ABLATION
-    if (getenv("MOT_BWD_ABL")) A.abl = atoi(getenv("MOT_BWD_ABL"));
-    if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
-#endif
-    size_t lds = (size_t)kBwdWaves * kMaxBpt * sizeof(float);
-    A.privatize = 0;
-    if (d.mode == MOT_MIX_SUM) {
-        const size_t tab = (size_t)d.byte_rows * d.byte_dim * sizeof(float);
-        if (tab + lds <= 150 * 1024) { A.privatize = 1; lds += tab; }
-        if (d.norm_byte) {
-            int rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rn, MOT_F32, stream);
-            if (rc) return rc;
-            A.byte_rnorm = rn;
-        }
-        return dispatch_ne<MOT_MIX_SUM>(A, lds, stream);
-    }
-    return dispatch_ne<MOT_MIX_NOOP>(A, lds, stream);
+    int32_t *ints = (int32_t *)(rn + bwd_rnorm_floats(d));
+    if (d.mode == MOT_MIX_SUM) return run_scatter<MOT_MIX_SUM>(A, d, ints, rn, stream);
+    return run_scatter<MOT_MIX_NOOP>(A, d, ints, rn, stream);
 }
 
 }  // namespace mot

@@ -172,7 +172,7 @@ int mot_embed_mix_bwd(const MotEmbedMixDesc *desc, const MotEmbedMixGrads *grads
     MotEmbedMixDesc d;
     if (!desc) return set_error(MOT_EINVAL, "embed_mix_bwd: null descriptor");
     d = *desc;
-    if (!d.out) d.out = (void *)grads->grad_out;  // the forward validator wants a non-null `out`; it is not touched
+    if (!d.out) d.out = (void *)grads->grad_out;  // the forward validator wants a non-null `out` (only CONCAT_LINEAR reads it)
     int rc = validate_embed_mix(&d);
     if (rc) return rc;
     if (d.dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: only MOT_F32 is built");

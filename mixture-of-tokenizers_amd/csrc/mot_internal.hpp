@@ -28,6 +28,7 @@ int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float
 size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream);         // SUM / MEAN / NOOP
 int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream);  // CONCAT_LINEAR
+int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuilt, int wt_cols, hipStream_t stream);
 size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d);
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hipStream_t stream);

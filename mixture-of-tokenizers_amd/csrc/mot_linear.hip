@@ -32,6 +32,7 @@ struct LinArgs {
     MixArgs M;
     const float *Wt;    // [Kpad, DmPad] k-major copy of the weight, zero padded
     const float *bias;  // [Dm] or null
+    float *row_rnorm;   // optional [n_rows*T]: the post-norm factor of every row (for the backward)
     int K, Kpad, Dm, DmPad, bytes_first, dual;
 };
 
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(kThreads, OCC) void embed_mix_linear_kernel(const L
                 const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float tot = ((S.rowss[m] + S.rowss[kTM + m]) + S.rowss[2 * kTM + m]) + S.rowss[3 * kTM + m];
                 const float rs = rms_scale(tot, P.Dm, A.eps);
+                if (P.row_rnorm && wave == 0 && li == 0 && m < ntok) P.row_rnorm[row * A.T + t0 + m] = rs;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] *= rs;
             }
@@ -371,7 +373,11 @@ static int launch_lin(LinArgs &P, const MotEmbedMixDesc &d, hipStream_t stream) 
     return check_launch("embed_mix_linear_kernel");
 }
 
-int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) {
+int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) { return launch_embed_mix_linear_ex(d, nullptr, 0, stream); }
+
+// `wt_prebuilt` (optional): the k-major, zero-padded weight operand [Kpad rows][wt_cols columns] supplied by
+// the caller (the backward passes W itself: for du = dy.W the nn.Linear layout already is k-major).
+int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuilt, int wt_cols, hipStream_t stream) {
     const int nt = nt_of(d.model_dim);
     if (nt < 0) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: model_dim %d > 1024 is not built", d.model_dim);
     if ((d.tok_dim & 3) || (d.byte_dim & 3))
@@ -385,17 +391,24 @@ int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) {
     P.bytes_first = d.bytes_first;
     P.dual = d.id_source == MOT_IDS_FROM_TTB ? d.add_padded != 0 : d.ids_b != nullptr;
     P.bias = (const float *)d.bias;
-    const size_t need = embed_mix_linear_workspace_bytes(d);
-    if (!d.workspace || d.workspace_bytes < need)
-        return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
-    float *Wt = (float *)d.workspace;
-    float *rn = Wt + (size_t)P.Kpad * P.DmPad;
-    P.Wt = Wt;
-    hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((P.Kpad + 31) / 32), (unsigned)((P.DmPad + 31) / 32)),
-                       dim3(kThreads), 0, stream, (const float *)d.weight, P.Dm, P.K, Wt, P.Kpad, P.DmPad);
-    int rc = check_launch("transpose_pad_kernel");
-    if (rc) return rc;
-    if (d.norm_byte && !P.dual) {
+    P.row_rnorm = d.norm_out ? d.out_row_rnorm : nullptr;
+    int rc;
+    float *rn = nullptr;
+    if (wt_prebuilt) {
+        if (wt_cols != P.DmPad) return set_error(MOT_EINVAL, "embed_mix concat_linear: prebuilt weight has %d columns, kernel wants %d", wt_cols, P.DmPad);
+        P.Wt = wt_prebuilt;
+    } else {
+        const size_t need = embed_mix_linear_workspace_bytes(d);
+        if (!d.workspace || d.workspace_bytes < need)
+            return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
+        float *Wt = (float *)d.workspace;
+        rn = Wt + (size_t)P.Kpad * P.DmPad;
+        P.Wt = Wt;
+        hipLaunchKernelGGL(transpose_pad_kernel, dim3((unsigned)((P.Kpad + 31) / 32), (unsigned)((P.DmPad + 31) / 32)),
+                           dim3(kThreads), 0, stream, (const float *)d.weight, P.Dm, P.K, Wt, P.Kpad, P.DmPad);
+        if ((rc = check_launch("transpose_pad_kernel"))) return rc;
+    }
+    if (d.norm_byte && !P.dual && rn) {
         rc = launch_rows_rnorm(P.M.byte_table, d.byte_rows, d.byte_dim, P.M.eps, rn, MOT_F32, stream);
         if (rc) return rc;
         P.M.byte_rnorm = rn;

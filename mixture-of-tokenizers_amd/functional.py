@@ -145,7 +145,7 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
               norm_tok: bool = False, norm_byte: bool = False, norm_out: bool = False, eps: float | None = None,
               scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
               out: torch.Tensor | None = None, return_ids: bool = False,
-              counters: torch.Tensor | None = None) -> torch.Tensor | MixResult:
+              counters: torch.Tensor | None = None, row_rnorm: torch.Tensor | None = None) -> torch.Tensor | MixResult:
     """One fused launch of mot_embed_mix_fwd; see include/mot.h for the per-token formula.
 
     tokens (B, T) integer.  Byte ids either come from `ttb` (+ `pull` = "left" | "right" | None,
@@ -231,6 +231,9 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
             raise ValueError("counters must be an int64[4] tensor on the inputs' device")
         d.counters = capi.ptr(counters)
     d.status = capi.ptr(capi.status_word(dev))
+    if row_rnorm is not None:   # (B, T) fp32, written by the concat_linear kernel when norm_out (saved for the backward)
+        assert row_rnorm.dtype == torch.float32 and row_rnorm.numel() == B * T and row_rnorm.is_contiguous()
+        d.out_row_rnorm = capi.ptr(row_rnorm)
     ws = _workspace(dev, capi.lib.mot_embed_mix_workspace_bytes(C.byref(d)))
     if ws is not None:
         d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
@@ -241,7 +244,7 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     return out
 
 
-_BWD_MODES = ("sum", "noop")
+_BWD_MODES = ("sum", "noop", "concat_linear")
 
 
 class _EmbedMixFn(torch.autograd.Function):
@@ -249,22 +252,29 @@ class _EmbedMixFn(torch.autograd.Function):
     mot_embed_mix_bwd launch (dense gradients, like nn.Embedding(sparse=False) in the reference)."""
 
     @staticmethod
-    def forward(ctx, tok_table, byte_table, scale_tok, scale_byte, tokens, kw):
+    def forward(ctx, tok_table, byte_table, scale_tok, scale_byte, weight, bias, tokens, kw):
         kw = dict(kw)
         mode = kw["mode"]
         want_ids = kw.get("ttb") is not None and mode != "noop"
         user_return_ids = kw.pop("return_ids", False)
+        kw.pop("weight", None); kw.pop("bias", None)
+        rn = None
+        if mode == "concat_linear" and kw.get("norm_out"):
+            t2 = tokens if tokens.ndim == 2 else tokens[None]
+            rn = torch.empty(t2.shape, dtype=torch.float32, device=tok_table.device)
         r = _embed_mix_fwd(tokens, tok_table.detach(), None if byte_table is None else byte_table.detach(),
                            scale_tok=None if scale_tok is None else scale_tok.detach(),
                            scale_byte=None if scale_byte is None else scale_byte.detach(),
-                           return_ids=want_ids or user_return_ids, **kw)
+                           weight=None if weight is None else weight.detach(), bias=None if bias is None else bias.detach(),
+                           return_ids=want_ids or user_return_ids, row_rnorm=rn, **kw)
         x = r.x if isinstance(r, MixResult) else r
         ids_a, ids_b = kw.get("ids_a"), kw.get("ids_b")
         if want_ids:   # the byte ids the kernel produced in LDS, written out once for the backward
             ids_a = r.ids_pulled if kw.get("pull") not in (None, "none") else r.ids_padded
             ids_b = r.ids_padded if kw.get("add_padded") else None
-        ctx.save_for_backward(tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b)
-        ctx.kw = {k: kw[k] for k in ("mode", "bpt", "norm_tok", "norm_byte", "norm_out", "eps") if k in kw}
+        ctx.save_for_backward(tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b, weight, bias,
+                              x if mode == "concat_linear" else None, rn)
+        ctx.kw = {k: kw[k] for k in ("mode", "bpt", "norm_tok", "norm_byte", "norm_out", "eps", "bytes_first") if k in kw}
         if user_return_ids:
             ctx.mark_non_differentiable(r.ids_padded, r.ids_pulled)
             return x, r.ids_padded, r.ids_pulled
@@ -272,14 +282,17 @@ class _EmbedMixFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gx, *_):
-        tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b = ctx.saved_tensors
+        tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b, weight, bias, x, rn = ctx.saved_tensors
         g = embed_mix_backward(gx, tokens, tok_table.detach(), None if byte_table is None else byte_table.detach(),
                                ids_a=ids_a, ids_b=ids_b,
                                scale_tok=None if scale_tok is None else scale_tok.detach(),
-                               scale_byte=None if scale_byte is None else scale_byte.detach(), **ctx.kw)
+                               scale_byte=None if scale_byte is None else scale_byte.detach(),
+                               weight=None if weight is None else weight.detach(), bias=None if bias is None else bias.detach(),
+                               out=None if x is None else x.detach(), row_rnorm=rn, **ctx.kw)
         return (g["tok_table"], g["byte_table"],
                 None if scale_tok is None else g["scale_tok"].reshape(scale_tok.shape),
-                None if scale_byte is None else g["scale_byte"].reshape(scale_byte.shape), None, None)
+                None if scale_byte is None else g["scale_byte"].reshape(scale_byte.shape),
+                g.get("weight"), g.get("bias"), None, None)
 
 
 @torch.compiler.disable
@@ -287,6 +300,8 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
                        mode: str, bpt: int = 0, ids_a: torch.Tensor | None = None, ids_b: torch.Tensor | None = None,
                        norm_tok: bool = False, norm_byte: bool = False, norm_out: bool = False, eps: float | None = None,
                        scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
+                       weight: torch.Tensor | None = None, bias: torch.Tensor | None = None, bytes_first: bool = False,
+                       out: torch.Tensor | None = None, row_rnorm: torch.Tensor | None = None,
                        into: dict | None = None) -> dict:
     """One launch of mot_embed_mix_bwd.  Returns dense fp32 gradients {tok_table, byte_table, scale_tok,
     scale_byte}; pass `into` (same keys) to accumulate into existing buffers such as ``param.grad``."""
@@ -306,6 +321,7 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
     d.tokens = capi.ptr(tok)
     d.tok_table, d.tok_rows, d.tok_dim, d.model_dim = capi.ptr(tt), tt.shape[0], tt.shape[1], tt.shape[1]
     into = into or {}
+    fwd_out = out
     out = {"tok_table": into.get("tok_table", None), "byte_table": into.get("byte_table", None),
            "scale_tok": into.get("scale_tok", None), "scale_byte": into.get("scale_byte", None)}
     if out["tok_table"] is None:
@@ -328,6 +344,24 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
         if out["byte_table"] is None:
             out["byte_table"] = torch.zeros_like(bt)
         gr.d_byte_table = capi.ptr(out["byte_table"])
+    if m == capi.MIX_CONCAT_LINEAR:
+        w = _contig(weight, torch.float32, "weight")
+        keep.append(w)
+        d.weight, d.model_dim, d.bytes_first = capi.ptr(w), w.shape[0], int(bytes_first)
+        out["weight"] = into.get("weight") if into.get("weight") is not None else torch.zeros_like(w)
+        gr.d_weight = capi.ptr(out["weight"])
+        if bias is not None:
+            bs = _contig(bias, torch.float32, "bias")
+            keep.append(bs)
+            d.bias = capi.ptr(bs)
+            out["bias"] = into.get("bias") if into.get("bias") is not None else torch.zeros_like(bs)
+            gr.d_bias = capi.ptr(out["bias"])
+        if norm_out:
+            if fwd_out is None or row_rnorm is None:
+                raise ValueError("concat_linear backward with norm_out needs the forward's output and row_rnorm")
+            xo = _contig(fwd_out, torch.float32, "out")
+            keep.append(xo)
+            d.out, d.out_row_rnorm = capi.ptr(xo), capi.ptr(row_rnorm)
     d.norm_tok, d.norm_byte, d.norm_out = int(norm_tok), int(norm_byte), int(norm_out)
     d.eps = float(eps or 0.0)
     d.scale_tok, d.scale_byte = capi.ptr(scale_tok), capi.ptr(scale_byte)
@@ -347,8 +381,8 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
 def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor | None = None, *,
               scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None, **kw):
     """The fused front-end (see `_embed_mix_fwd` for the arguments).  With autograd enabled and
-    differentiable parameters it records one backward node (modes "sum" and "noop"; the
-    concat+linear backward is a later scope row and raises)."""
+    differentiable parameters it records one backward node (modes "sum", "noop", "concat_linear";
+    fp32 tables)."""
     params = (tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"))
     if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
         if kw["mode"] not in _BWD_MODES:
@@ -360,7 +394,9 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
         if tok_table.dtype != torch.float32:
             raise RuntimeError("mixture-of-tokenizers_amd: the backward is built for float32 tables only; "
                                "use torch.no_grad() with bfloat16 tables")
-        r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, tokens, kw)
+        if kw.get("norm_byte") and (kw.get("ids_b") is not None or kw.get("add_padded")):
+            raise RuntimeError("mixture-of-tokenizers_amd: backward of norm(emb(padded) + emb(pulled)) is not built yet")
+        r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"), tokens, kw)
         if kw.get("return_ids"):
             return MixResult(*r)
         return r

@@ -18,10 +18,10 @@ mixes and writes x.  Anything that needs the tensors themselves calls ``handle.m
 Parameters are read from their live storage at launch time, so weight tying
 (``wte.weight = lm_head.weight``, model.py:316-317) and in-place optimizer updates are honoured.
 
-Autograd: the gather + sum family (SumFrontEnd, the tokens-only / noop paths) is differentiable --
-one fused backward launch produces the dense table gradients.  The concat + linear mixin is forward
-only this round: with autograd enabled on parameters that require grad it raises instead of silently
-dropping the graph.
+Autograd: the fused paths (sum, tokens-only/noop, concat + linear) are differentiable with fp32
+parameters: one backward call produces the dense table / weight / bias / scalar gradients.  What is
+not built raises instead of silently dropping the graph: bf16 parameters, the materialised
+(non-fused) seam tensors, and norm(emb(padded) + emb(pulled)) (add_padded_and_pulled).
 """
 from __future__ import annotations
 
@@ -201,7 +201,6 @@ def _mix_concat(h_or_tok, byte_embs, *, bpt: int, weight: Tensor, bias: Tensor |
     kernel over the already materialised seam tensors (rows addressed by arange ids)."""
     if isinstance(h_or_tok, EmbedHandle):
         h = h_or_tok
-        _check_forward_only(h.tok_weight, h.byte_weight, weight, bias)
         return F_mot.embed_mix(h.tokens, _f32(h.tok_weight, "token table"), _f32(h.byte_weight, "byte table"),
                                mode="concat_linear", bpt=h.bpt, ids_a=h.ids_a.reshape(h.tokens.shape[0], -1),
                                ids_b=None if h.ids_b is None else h.ids_b.reshape(h.tokens.shape[0], -1),
@@ -271,7 +270,6 @@ class FusedFrontEnd(nn.Module):
         bp, emb = self.byte_params, self.embed
         if bp.byte_mixin_method == "noop":
             return self.byte_mixin(*emb(tokens, None, None))
-        _check_forward_only(emb.embed_tokens.weight, emb.embed_bytes.weight, self.byte_mixin.mixin.mixin.weight)
         pull = None if not bp.pull_in else bp.padding_in          # left-padded bytes are pulled from the left
         return F_mot.embed_mix(tokens, _f32(emb.embed_tokens.weight, "token table"), _f32(emb.embed_bytes.weight, "byte table"),
                                mode="concat_linear", bpt=bp.bytes_per_token, ttb=self.ttb, pull=pull,

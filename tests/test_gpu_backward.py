@@ -79,15 +79,106 @@ def test_noop_backward_vs_reference_autograd(mot):
     assert rel(host(embed.embed_tokens.weight.grad), z["scaled/noop/f64/d_tok"]) < TOL
 
 
-def test_concat_backward_is_refused_loudly(mot):
+SCALED_SMALL = ("small", 97, 32, 8, 64, 8, 2, 16, 401)
+
+
+@pytest.mark.parametrize("mode", ["padded", "pulled"])
+def test_concat_backward_vs_reference_autograd(mot, mode):
+    """loss.backward() through FlexibleEmbedding + ByteMixin(concat) (train_gpt.py:605-606, 1319) against the
+    gradients autograd produced for the reference modules: embed tables, mixin weight."""
     from mixture_of_tokenizers_amd import modules as M
-    bp = M.ByteHyperparameters(bytes_per_token=8, byte_mixin_method="concat")
+    name, Vt, Dt, Db, Dm, bpt, B, T, seed = SCALED_SMALL
+    z, zf = np.load(G / "grads.npz"), np.load(G / "float_scaled.npz")
+    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=mode == "pulled")
+    dims = M.ModelDims(model_dim=Dm, byte_dim=Db, token_dim=Dt)
+    embed, mixin = M.FlexibleEmbedding(dims, Vt, bp).to(DEV), M.ByteMixin(dims, T, bp).to(DEV)
+    with torch.no_grad():
+        embed.embed_tokens.weight.copy_(dev(f32(gi.normal_table(seed + 1, Vt, Dt))))
+        embed.embed_bytes.weight.copy_(dev(f32(gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db))))
+        mixin.mixin.mixin.weight.copy_(dev(f32(gi.casted_linear_weight(seed + 3, Dm, Dt + bpt * Db))))
+    x = mixin(*embed(tokens=dev(zf[f"{name}/tokens"]), byte_tensor=dev(zf[f"{name}/padded"]), byte_tensor_pulled=dev(zf[f"{name}/pulled"])))
+    assert x.requires_grad
+    (x * dev(f32(z["scaled/g"]))).sum().backward()
+    assert rel(host(embed.embed_tokens.weight.grad), z[f"scaled/{mode}/f64/d_tok"]) < TOL
+    assert rel(host(embed.embed_bytes.weight.grad), z[f"scaled/{mode}/f64/d_byte"]) < TOL
+    assert rel(host(mixin.mixin.mixin.weight.grad), z[f"scaled/{mode}/f64/d_W"]) < TOL
+
+
+def test_concat_backward_unbuilt_combination_is_refused(mot):
+    """norm(emb(padded) + emb(pulled)) (add_padded_and_pulled) has no backward yet: it must say so."""
+    from mixture_of_tokenizers_amd import modules as M
+    bp = M.ByteHyperparameters(bytes_per_token=8, byte_mixin_method="concat", pull_in=True, add_padded_and_pulled=True)
     dims = M.ModelDims(model_dim=64, byte_dim=8, token_dim=32)
     embed, mixin = M.FlexibleEmbedding(dims, 97, bp).to(DEV), M.ByteMixin(dims, 16, bp).to(DEV)
     toks = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
     ids = torch.zeros((1, 32), dtype=torch.int64, device=DEV)
-    with pytest.raises(RuntimeError, match="forward"):
+    with pytest.raises(RuntimeError, match="not built"):
         mixin(*embed(toks, ids, ids))
+    with torch.no_grad():
+        assert mixin(*embed(toks, ids, ids)).shape == (1, 4, 64)
+
+
+def test_mathblations_backward_vs_reference_autograd(mot):
+    """DigitFrontEnd (wte tied to an lm_head Parameter, dte, fc with bias, digits first) under autograd:
+    the gradient lands on the shared Parameter exactly as in model.py:316-317."""
+    from mixture_of_tokenizers_amd import modules as M
+    z = np.load(G / "grads.npz")
+    D = 32
+    fe = M.DigitFrontEnd(M.GPTConfig(vocab_size=1003, n_embd_tok=D, n_embd_digit=D, length_factor=3, digit_mixin_method="concat")).to(DEV)
+    lm_head = torch.nn.Linear(D, 1003, bias=False).to(DEV)
+    fe.wte.weight = lm_head.weight
+    Wf, bf = gi.linear_weight_bias(613, D, 4 * D)
+    with torch.no_grad():
+        lm_head.weight.copy_(dev(f32(gi.normal_table(611, 1003, D))))
+        fe.dte.weight.copy_(dev(f32(gi.normal_table(612, 14, D))))
+        fe.digit_mixin.fc.weight.copy_(dev(f32(Wf))); fe.digit_mixin.fc.bias.copy_(dev(f32(bf)))
+    x = fe(dev(z["math/x_tokens"]), dev(z["math/x_digit_tokens"]))
+    (x * dev(f32(z["math/g"]))).sum().backward()
+    assert rel(host(lm_head.weight.grad), z["math/f64/d_tok"]) < TOL
+    assert rel(host(fe.dte.weight.grad), z["math/f64/d_byte"]) < TOL
+    assert rel(host(fe.digit_mixin.fc.weight.grad), z["math/f64/d_W"]) < TOL
+    assert rel(host(fe.digit_mixin.fc.bias.grad), z["math/f64/d_bias"]) < TOL
+
+
+@pytest.mark.parametrize("Dt,Db,bpt,Dm,Vt,B,T,kw,seed", [
+    (256, 32, 16, 768, 4096, 2, 512, dict(norm_tok=True, norm_byte=True, norm_out=True), 9201),     # C2-CONCAT dims
+    (256, 48, 16, 1024, 2048, 2, 160, dict(norm_tok=True, norm_byte=True, norm_out=True), 9202),    # production dims
+    (128, 32, 8, 200, 512, 2, 77, dict(norm_tok=True, bias=True), 9203),                            # ragged Dm, bias, no out norm
+    (256, 256, 3, 256, 1003, 8, 32, dict(bias=True, bytes_first=True), 9204),                       # mathblations dims
+    (100, 20, 5, 384, 512, 2, 130, dict(norm_byte=True, norm_out=True, bytes_first=True, scaled=True), 9205),
+])
+def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
+    kw = dict(kw)
+    scaled, use_bias = kw.pop("scaled", False), kw.pop("bias", False)
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=min(4.4, bpt / 2))
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, Dt)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    K = Dt + bpt * Db
+    W = f32(gi.casted_linear_weight(seed + 4, Dm, K))
+    bias = f32(gi.linear_weight_bias(seed + 5, Dm, K)[1]) if use_bias else None
+    g = f32(np.random.RandomState(seed + 6).standard_normal((B, T, Dm)))
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    okw = dict(kw)
+    dEt, dEb, dW = (torch.nn.Parameter(dev(a)) for a in (Et, Eb, W))
+    dbias = torch.nn.Parameter(dev(bias)) if use_bias else None
+    gkw = dict(kw)
+    if scaled:
+        okw.update(scale_tok=1.3, scale_byte=0.6)
+        st, sb = torch.nn.Parameter(torch.tensor([1.3], device=DEV)), torch.nn.Parameter(torch.tensor([0.6], device=DEV))
+        gkw.update(scale_tok=st, scale_byte=sb)
+    ref = orc.embed_mix_bwd(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
+                            mode="concat_linear", bpt=bpt, weight=W.astype(np.float64),
+                            bias=None if bias is None else bias.astype(np.float64), dtype=np.float64, **okw)
+    x = mot.embed_mix(dev(toks), dEt, dEb, mode="concat_linear", bpt=bpt, ttb=dev(tab), pull="left", weight=dW, bias=dbias, **gkw)
+    (x * dev(g)).sum().backward()
+    assert rel(host(dEt.grad), ref["tok_table"]) < TOL
+    assert rel(host(dEb.grad), ref["byte_table"]) < TOL
+    assert rel(host(dW.grad), ref["weight"]) < TOL
+    if use_bias:
+        assert rel(host(dbias.grad), ref["bias"]) < TOL
+    if scaled:
+        assert abs(float(st.grad) - ref["scales"][0]) < TOL * abs(ref["scales"]).max()
+        assert abs(float(sb.grad) - ref["scales"][1]) < TOL * abs(ref["scales"]).max()
 
 
 @pytest.mark.parametrize("D,Db,bpt,Vt,B,T,kw,seed", [

@@ -69,7 +69,7 @@ def test_scaled_pretrain_modules(M, case, fused):
     assert_close(host(net(toks, None, None)), z[f"{name}/noop/f32/x"])
 
 
-def test_fused_front_end_and_grad_guard(M):
+def test_fused_front_end(M):
     name, Vt, Dt, Db, Dm, bpt, B, T, seed = SCALED[1]
     z = np.load(G / "float_scaled.npz")
     bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=True)
@@ -79,8 +79,8 @@ def test_fused_front_end_and_grad_guard(M):
     fe.embed.embed_tokens.weight.data.copy_(dev(f32(gi.normal_table(seed + 1, Vt, Dt))))
     fe.embed.embed_bytes.weight.data.copy_(dev(f32(gi.normal_table(seed + 2, gi.BYTE_VOCAB, Db))))
     fe.byte_mixin.mixin.mixin.weight.data.copy_(dev(f32(gi.casted_linear_weight(seed + 3, Dm, Dt + bpt * Db))))
-    with pytest.raises(RuntimeError, match="forward of the embedding front-end only"):
-        fe(dev(z[f"{name}/tokens"]))
+    y = fe(dev(z[f"{name}/tokens"]))                       # autograd on: records one backward node
+    assert y.requires_grad and y.grad_fn is not None
     with torch.no_grad():
         r = fe(dev(z[f"{name}/tokens"]), return_ids=True)
     np.testing.assert_array_equal(host(r.ids_pulled), z[f"{name}/pulled"])
