@@ -155,9 +155,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # MOT_FORCE_DIST=1 exercises the multi-rank code path (RCCL init, barrier, all-reduce) with a single rank
+    use_dist = world > 1 or os.environ.get("MOT_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local_rank)
@@ -204,7 +208,7 @@ def main():
                           scale_byte=lc, out=out, counters=cnt)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -226,7 +230,7 @@ def main():
     mot.check_status()
 
     tokens_per_step = B * T
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -298,7 +302,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, inp, args.cpu_seconds)
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

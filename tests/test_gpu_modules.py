@@ -203,3 +203,30 @@ def test_make_embedding_reproduces_reference_quirk(tmp_path, monkeypatch):
     with torch.no_grad():
         emb.weight[50256] = 457.0                                            # the table cache follows in-place edits
     assert host(dc.tokens_to_bytes(dev(z["tokens"]), emb)).reshape(4, 8)[2].tolist() == [457] * 8
+
+
+def test_training_steps_reduce_the_loss(M):
+    """The point of a drop-in: a few optimizer steps through the fused modules (forward + backward kernels,
+    torch.optim on the same Parameters the reference groups by name, train_gpt.py:1154-1157) lower a loss."""
+    torch.manual_seed(0)
+    Vt, Dt, Db, Dm, bpt, B, T = 512, 64, 16, 128, 8, 4, 64
+    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=True)
+    net = Host(M, M.ModelDims(model_dim=Dm, byte_dim=Db, token_dim=Dt), Vt, bp).to(DEV)
+    from mixture_of_tokenizers_amd import data_creation as dc
+    tab = dev(gi.synth_ttb(5, Vt, bpt, "left"))
+    toks = dev(gi.fineweb_like_tokens(6, B, T, vocab=Vt, eot_p=0.02))
+    padded = dc.tokens_to_bytes(toks, tab)
+    pulled = dc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    target = torch.randn(B, T, Dm, device=DEV)
+    opt = torch.optim.Adam([p for n, p in net.named_parameters()], lr=0.05)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad(set_to_none=True)
+        xt, xb = net.embed(tokens=toks, byte_tensor=padded, byte_tensor_pulled=pulled)
+        x = net.byte_mixin(xt, xb)
+        loss = ((x - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    assert losses[-1] < 0.8 * losses[0], losses
