@@ -34,8 +34,6 @@ static int validate_embed_mix(const MotEmbedMixDesc *d) {
     if (d->struct_size != sizeof(MotEmbedMixDesc))
         return set_error(MOT_EINVAL, "embed_mix: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(MotEmbedMixDesc));
     if (d->dtype != MOT_F32 && d->dtype != MOT_BF16) return set_error(MOT_EINVAL, "embed_mix: bad dtype %d", d->dtype);
-    if (d->dtype == MOT_BF16 && d->mode == MOT_MIX_CONCAT_LINEAR)
-        return set_error(MOT_EUNSUPPORTED, "embed_mix: the bf16 concat_linear (bf16 MFMA) kernel is not built yet");
     if (d->n_rows < 0 || d->tokens_per_row < 0) return set_error(MOT_ESHAPE, "embed_mix: negative shape");
     if (d->mode < MOT_MIX_NOOP || d->mode > MOT_MIX_CONCAT_LINEAR) return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d->mode);
     if (!d->tokens || !d->tok_table || !d->out) return set_error(MOT_EINVAL, "embed_mix: tokens/tok_table/out must be non-null");
@@ -187,7 +185,8 @@ int mot_embed_mix_fwd(const MotEmbedMixDesc *desc, mot_stream_t stream) {
     int rc = validate_embed_mix(desc);
     if (rc) return rc;
     if (desc->n_rows == 0 || desc->tokens_per_row == 0) return MOT_OK;
-    if (desc->mode == MOT_MIX_CONCAT_LINEAR) return launch_embed_mix_linear(*desc, (hipStream_t)stream);
+    if (desc->mode == MOT_MIX_CONCAT_LINEAR)
+        return desc->dtype == MOT_BF16 ? launch_embed_mix_linear_bf16(*desc, (hipStream_t)stream) : launch_embed_mix_linear(*desc, (hipStream_t)stream);
     return launch_embed_mix(*desc, (hipStream_t)stream);
 }
 

@@ -290,7 +290,7 @@ int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float
 }
 
 size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d) {
-    if (d.mode == MOT_MIX_CONCAT_LINEAR) return embed_mix_linear_workspace_bytes(d);
+    if (d.mode == MOT_MIX_CONCAT_LINEAR) return d.dtype == MOT_BF16 ? embed_mix_linear_bf16_workspace_bytes(d) : embed_mix_linear_workspace_bytes(d);
     if (d.mode != MOT_MIX_NOOP && d.norm_byte) return (size_t)d.byte_rows * sizeof(float);
     return 0;
 }

@@ -30,6 +30,8 @@ int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream);         // S
 int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream);  // CONCAT_LINEAR
 int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuilt, int wt_cols, hipStream_t stream);
 size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d);
+size_t embed_mix_linear_bf16_workspace_bytes(const MotEmbedMixDesc &d);
+int launch_embed_mix_linear_bf16(const MotEmbedMixDesc &d, hipStream_t stream);
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hipStream_t stream);
 

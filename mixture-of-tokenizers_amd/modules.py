@@ -201,6 +201,9 @@ def _mix_concat(h_or_tok, byte_embs, *, bpt: int, weight: Tensor, bias: Tensor |
     kernel over the already materialised seam tensors (rows addressed by arange ids)."""
     if isinstance(h_or_tok, EmbedHandle):
         h = h_or_tok
+        if h.tok_weight.dtype != weight.dtype:   # CastedLinear.forward: self.weight.type_as(x)  (train_gpt.py:185-186)
+            weight = weight.to(h.tok_weight.dtype)
+            bias = None if bias is None else bias.to(h.tok_weight.dtype)
         return F_mot.embed_mix(h.tokens, _f32(h.tok_weight, "token table"), _f32(h.byte_weight, "byte table"),
                                mode="concat_linear", bpt=h.bpt, ids_a=h.ids_a.reshape(h.tokens.shape[0], -1),
                                ids_b=None if h.ids_b is None else h.ids_b.reshape(h.tokens.shape[0], -1),

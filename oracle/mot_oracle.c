@@ -263,6 +263,16 @@ int oracle_rank_slice_shift(const int32_t *data, int64_t pos, int64_t batch,
 static double g_eps_override = 0.0;
 void oracle_set_eps(double eps) { g_eps_override = eps; }
 
+/* bf16 matmul path (train_gpt.py:185-186 + 1124-1126): the normalised/scaled segments are bf16 TENSORS
+ * when they enter F.linear, so the concat operand is rounded to bf16 (nearest-even) element by element. */
+static int g_round_seg_bf16 = 0;
+void oracle_set_round_segments_bf16(int on) { g_round_seg_bf16 = on; }
+static double bf16_rne(double x) {
+    float f = (float)x; uint32_t u; memcpy(&u, &f, 4);
+    u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+    memcpy(&f, &u, 4); return (double)f;
+}
+
 /* mixing modes (values shared with nothing in the product on purpose) */
 #define O_MODE_NOOP 0          /* x = tok part only                                  */
 #define O_MODE_SUM 1           /* x = a + concat_k b_k   (runs/71*.py:227-230)       */

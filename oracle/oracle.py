@@ -55,6 +55,11 @@ def set_eps(eps: float) -> None:
     lib().oracle_set_eps(C.c_double(eps))
 
 
+def set_round_segments_bf16(on: bool) -> None:
+    """Round the (normalised, scaled) concat operand to bf16 before the contraction: the bf16 F.linear path."""
+    lib().oracle_set_round_segments_bf16(C.c_int(int(on)))
+
+
 def bf16_round(a) -> np.ndarray:
     """Round float32/float64 values to the nearest bfloat16 (ties to even), returned as float32."""
     x = np.ascontiguousarray(a, dtype=np.float32)

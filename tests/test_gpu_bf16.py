@@ -95,6 +95,61 @@ def test_bf16_limits(mot):
     ids = torch.zeros((1, 32), dtype=torch.int64, device=DEV)
     with pytest.raises(TypeError):      # mixed table dtypes
         mot.embed_mix(toks, Et, Eb, mode="sum", bpt=8, ids_a=ids)
-    with pytest.raises(NotImplementedError, match="bf16 MFMA"):
-        mot.embed_mix(toks, Et, Eb.bfloat16(), mode="concat_linear", bpt=8, ids_a=ids,
-                      weight=torch.zeros(64, 128, device=DEV, dtype=torch.bfloat16))
+
+
+
+# ------------------------------------------------------------------------------------------------
+# concat + linear in bf16 (bf16 MFMA, fp32 accumulate): the production dtype of ByteMixinConcat.
+# Oracle: float64 on the bf16-valued tables / weight with the concat operand rounded to bf16 (what F.linear
+# receives), eps = 2^-7, result rounded once.  Bar: within 2 bf16 steps (fp32 accumulation order differs from
+# the float64 oracle by ~1e-6 relative, which moves a handful of results across a rounding boundary twice:
+# once at the segment rounding, once at the output), > 97 % identical.
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Dt,Db,bpt,Dm,Vt,B,T,kw,seed", [
+    (256, 32, 16, 768, 4096, 2, 512, dict(norm_tok=True, norm_byte=True, norm_out=True), 9601),     # C2-CONCAT dims
+    (256, 48, 16, 1024, 2048, 2, 200, dict(norm_tok=True, norm_byte=True, norm_out=True), 9602),    # production dims
+    (64, 16, 8, 128, 512, 3, 100, dict(norm_out=True), 9603),
+    (256, 256, 3, 256, 1003, 8, 32, dict(bias=True, bytes_first=True), 9604),                       # mathblations dims
+    (104, 24, 5, 384, 512, 2, 130, dict(norm_byte=True, norm_out=True, bytes_first=True), 9605),    # K = 224: ragged last K-step
+])
+def test_bf16_concat_linear_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
+    kw = dict(kw)
+    use_bias = kw.pop("bias", False)
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=min(4.4, bpt / 2))
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = orc.bf16_round(gi.normal_table(seed + 2, Vt, Dt)), orc.bf16_round(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    K = Dt + bpt * Db
+    W = orc.bf16_round(gi.casted_linear_weight(seed + 4, Dm, K))
+    bias = orc.bf16_round(gi.linear_weight_bias(seed + 5, Dm, K)[1]) if use_bias else None
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    orc.set_eps(2.0 ** -7); orc.set_round_segments_bf16(True)
+    try:
+        ref = orc.embed_mix(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), mode="concat_linear", bpt=bpt,
+                            weight=W.astype(np.float64), bias=None if bias is None else bias.astype(np.float64), dtype=np.float64, **kw)
+    finally:
+        orc.set_eps(0.0); orc.set_round_segments_bf16(False)
+    b16 = lambda a: None if a is None else dev(a).bfloat16()
+    x = mot.embed_mix(dev(toks), b16(Et), b16(Eb), mode="concat_linear", bpt=bpt, ttb=dev(tab), pull="left", weight=b16(W),
+                      bias=b16(bias), **kw)
+    assert x.dtype == torch.bfloat16 and x.shape == (B, T, Dm)
+    got, want = host(x.float()), orc.bf16_round(ref)
+    assert ulps(got, want).max() <= 2
+    assert (got == want).mean() > 0.97
+
+
+def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
+    """nn.Embedding tables in bf16 (train_gpt.py:1124-1126), fp32 master weight cast per call (:185-186)."""
+    from mixture_of_tokenizers_amd import modules as M
+    Vt, Dt, Db, Dm, bpt, B, T = 512, 64, 16, 128, 8, 2, 64
+    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=True)
+    dims = M.ModelDims(model_dim=Dm, byte_dim=Db, token_dim=Dt)
+    embed, mixin = M.FlexibleEmbedding(dims, Vt, bp).to(DEV), M.ByteMixin(dims, T, bp).to(DEV)
+    for m in embed.modules():
+        if isinstance(m, torch.nn.Embedding):
+            m.bfloat16()
+    assert mixin.mixin.mixin.weight.dtype == torch.float32
+    toks = dev(gi.fineweb_like_tokens(1, B, T, vocab=Vt))
+    ids = torch.randint(0, gi.BYTE_VOCAB, (B, T * bpt), device=DEV)
+    with torch.no_grad():
+        x = mixin(*embed(toks, ids, ids))
+    assert x.dtype == torch.bfloat16 and x.shape == (B, T, Dm) and bool(torch.isfinite(x.float()).all())
