@@ -143,7 +143,7 @@ def cpu_baseline(wl, inp, seconds):
         once()
         reps += 1
         el = time.perf_counter() - t0
-        if el >= seconds or reps >= 200:
+        if el >= seconds or reps >= 5000:
             break
     return dict(value=rows * T * reps / el, unit="tokens/s", cores=cores, kind="port",
                 sample=f"{reps} passes over {rows}x{T} tokens of the same workload in {el:.1f} s "
@@ -276,8 +276,10 @@ def main():
         if mode == "concat_linear":   # dense contraction: priced against the fp32 matrix peak, not HBM
             K = WORKLOADS[wl][8] + bpt * Db
             tf = 2.0 * K * D * tokens_per_step / (kernel_ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": tf / F32_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": "embed_mix_linear_kernel",
+            peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
+            res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
+                               "frac": tf / peak, "traffic": traffic,
+                               "kernel": "embed_mix_linear_kernel" if args.dtype == "f32" else "embed_mix_linear_bf16_kernel",
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
         if args.backward and mode == "sum" and args.dtype == "f32":
             from mixture_of_tokenizers_amd import data_creation as dc
