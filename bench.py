@@ -183,29 +183,29 @@ def main():
     if mode == "sum":
         tab = torch.from_numpy(inp["tab"]).to(device)
         if args.ids == "fused":
-            def step(cnt=None):
-                mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="sum", bpt=bpt, ttb=tab, pull="left",
-                              norm_out=True, out=out, counters=cnt)
+            kwf = dict(mode="sum", bpt=bpt, ttb=tab, pull="left", norm_out=True, out=out)
         else:
             from mixture_of_tokenizers_amd import data_creation as dc
             ids = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
 
-            def step(cnt=None):
-                mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="sum", bpt=bpt, ids_a=ids, norm_out=True,
-                              out=out, counters=cnt)
+            kwf = dict(mode="sum", bpt=bpt, ids_a=ids, norm_out=True, out=out)
     elif mode == "concat_linear":
         tab = torch.from_numpy(inp["tab"]).to(device)
 
-        def step(cnt=None):
-            mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="concat_linear", bpt=bpt, ttb=tab, pull="left",
-                          weight=inp["weight"], norm_tok=True, norm_byte=True, norm_out=True, out=out, counters=cnt)
+        kwf = dict(mode="concat_linear", bpt=bpt, ttb=tab, pull="left", weight=inp["weight"], norm_tok=True, norm_byte=True,
+                   norm_out=True, out=out)
     else:
         chars = torch.from_numpy(inp["chars"]).to(device)
         lt, lc = torch.tensor(1.0, device=device), torch.tensor(0.5, device=device)
 
-        def step(cnt=None):
-            mot.embed_mix(toks, inp["tok_table"], inp["byte_table"], mode="mean", bpt=bpt, ids_a=chars, scale_tok=lt,
-                          scale_byte=lc, out=out, counters=cnt)
+        kwf = dict(mode="mean", bpt=bpt, ids_a=chars, scale_tok=lt, scale_byte=lc, out=out)
+
+    # one bound descriptor per variant: a step is exactly one mot_embed_mix_fwd call on the current stream
+    plan = mot.embed_mix_plan(toks, inp["tok_table"], inp["byte_table"], **kwf)
+    plan_cnt = mot.embed_mix_plan(toks, inp["tok_table"], inp["byte_table"], counters=counters, **kwf)
+
+    def step(cnt=None):
+        (plan if cnt is None else plan_cnt)()
 
     def barrier():
         if use_dist:

@@ -15,9 +15,9 @@ shim at the repo root maps that name onto this directory).
 from . import _capi
 from . import data_creation, functional, loader, modules
 from ._capi import build_info, check_status, set_debug_ids
-from .functional import create_batch, embed_mix, gather_rows, pull_bytes, tokens_to_bytes
+from .functional import create_batch, embed_mix, embed_mix_plan, gather_rows, pull_bytes, tokens_to_bytes
 
 __all__ = [
     "build_info", "check_status", "set_debug_ids", "data_creation", "functional", "loader", "modules",
-    "create_batch", "embed_mix", "gather_rows", "pull_bytes", "tokens_to_bytes",
+    "create_batch", "embed_mix", "embed_mix_plan", "gather_rows", "pull_bytes", "tokens_to_bytes",
 ]
