@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--ids", default="fused", choices=["fused", "given"],
                     help="fused: byte ids produced inside the kernel; given: int64 ids precomputed (module-level path)")
     ap.add_argument("--uniform-ids", action="store_true", help="uniform token ids (no-reuse worst case)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every rank runs the full per-GPU batch; strong: the workload's B rows are split over the ranks "
+                         "(config 4 as worded: one 256x2048 batch sharded over the GPUs, train_gpt.py:795-805)")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="table/output element type (compute is fp32)")
     ap.add_argument("--backward", action="store_true", help="also time the backward launch (sum workloads) and report it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -59,9 +62,10 @@ def parse():
     return ap.parse_args()
 
 
-def make_inputs(wl, device, seed, uniform):
+def make_inputs(wl, device, seed, uniform, rows=None):
     import golden_inputs as gi
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
+    B = rows or B
     Dt = WORKLOADS[wl][8] if mode == "concat_linear" else D
     g = torch.Generator(device=device).manual_seed(seed)
     tok_table = torch.randn((vocab, Dt), generator=g, device=device, dtype=torch.float32)
@@ -170,7 +174,10 @@ def main():
     import mixture_of_tokenizers_amd as mot
     wl = args.workload
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
-    inp = make_inputs(wl, device, seed=12345 + rank, uniform=args.uniform_ids)   # loader default seed, train_gpt.py:661
+    if args.scaling == "strong":
+        assert B % world == 0, "batch_size % world_size == 0 (train_gpt.py:795)"
+        B //= world
+    inp = make_inputs(wl, device, seed=12345 + rank, uniform=args.uniform_ids, rows=B)   # loader default seed, train_gpt.py:661
     toks = torch.from_numpy(inp["toks"]).to(device)
     esize = 4
     if args.dtype == "bf16":
@@ -258,7 +265,7 @@ def main():
             "unit": "tokens/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 tables/output, f32 arithmetic", "data": "synthetic",
             "config": {"workload": f"{wl}: BxT={B}x{T} per GPU, vocab {vocab}, bpt {bpt}, d_model {D}, byte_dim {Db}, "
                                    f"mode {mode}+rmsnorm, ids {args.ids}, token ids "

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
     const int nbyte = A.privatize ? (int)A.byte_rows * A.Db : 0;
     float *dbyte_l = lds_f;                           // [byte_rows*Db]
     float *seg = lds_f + nbyte + wave * kMaxBpt;      // per-wave per-slot dot products
+    float *segr = lds_f + nbyte + (kBwdWaves + wave) * kMaxBpt;  // per-wave per-slot rms factor (two-id-tensor norm)
     for (int i = tid; i < nbyte; i += kBwdThreads) dbyte_l[i] = 0.f;
     __syncthreads();
 
@@ -77,6 +78,8 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
     const int Dt = A.Dt;
     auto tok_off = [&](int e) { const int o = e - A.tok_lo; return (e < D && (unsigned)o < (unsigned)Dt) ? o : -1; };
     auto byte_off = [&](int e) { const int o = e - A.byte_lo; return (MODE != MOT_MIX_NOOP && e < D && (unsigned)o < (unsigned)A.nbk) ? o : -1; };
+    // norm over the sum of two embeddings only exists in front of the concat mixin (train_gpt.py:378, 443)
+    const bool pair_norm = MODE == MOT_MIX_CONCAT_LINEAR && A.norm_byte && A.ids_b;
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     float ds_t = 0.f, ds_b = 0.f;
@@ -156,8 +159,27 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
                     if ((uint64_t)ib >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); ib = 0; }
                     v += A.byte_table[ib * A.Db + wi];
                 }
-                if (A.norm_byte) v *= A.byte_rnorm[id1[j]];
+                if (A.norm_byte && !pair_norm) v *= A.byte_rnorm[id1[j]];
                 bn[j] = v;  // normalised, unscaled
+            }
+        }
+        if (pair_norm) {
+            // norm(emb(padded) + emb(pulled)) (train_gpt.py:378): the rms factor belongs to the (token, slot) pair,
+            // not to a table row -- reduce sum(b^2) per slot through the wave's LDS accumulators
+            if (lane < A.bpt) segr[lane] = 0.f;
+            __threadfence_block();
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int eb = byte_off(lane + 64 * j);
+                if (eb >= 0) atomicAdd(&segr[slot_of(eb)], bn[j] * bn[j]);
+            }
+            __threadfence_block();
+            if (lane < A.bpt) segr[lane] = rms_scale(segr[lane], A.Db, A.eps);
+            __threadfence_block();
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int eb = byte_off(lane + 64 * j);
+                if (eb >= 0) bn[j] *= segr[slot_of(eb)];
             }
         }
         tok_nx = load_tok(n_nx);
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
                 const int sl = slot_of(eb), wi = eb - sl * A.Db;
                 const float db = dy[j] * s_byte;
                 float v = db;
-                if (A.norm_byte) v = A.byte_rnorm[id1[j]] * (db - bn[j] * (seg[sl] / (float)A.Db));
+                if (A.norm_byte) v = (pair_norm ? segr[sl] : A.byte_rnorm[id1[j]]) * (db - bn[j] * (seg[sl] / (float)A.Db));
                 // two explicit address spaces (ds_add_f32 / global_atomic_add_f32): a pointer that may be
                 // either would become a flat atomic, which faults on the LDS aperture
                 const int i1 = id1[j] * A.Db + wi;
@@ -346,12 +368,12 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     if (getenv("MOT_BWD_ABL")) A.abl = atoi(getenv("MOT_BWD_ABL"));
     if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
 #endif
-    size_t lds = (size_t)kBwdWaves * kMaxBpt * sizeof(float);
+    size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float);
     A.privatize = 0;
     if (MODE != MOT_MIX_NOOP) {
         const size_t tab = (size_t)d.byte_rows * d.byte_dim * sizeof(float);
         if (tab + lds <= 150 * 1024) { A.privatize = 1; lds += tab; }
-        if (d.norm_byte) {
+        if (d.norm_byte && !(MODE == MOT_MIX_CONCAT_LINEAR && d.ids_b)) {
             rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rnorm_ws, MOT_F32, stream);
             if (rc) return rc;
             A.byte_rnorm = rnorm_ws;
@@ -543,7 +565,6 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     const int64_t N = d.n_rows * d.tokens_per_row;
     const int Dm = d.model_dim, Dt = d.tok_dim, nbk = d.bpt * d.byte_dim, K = Dt + nbk;
     if (K > 1024 || Dm > 2048) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 or model_dim %d > 2048", K, Dm);
-    if (d.ids_b && d.norm_byte) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: norm over two id tensors is forward-only so far");
     const LinBwdLayout L = lin_bwd_layout(d);
     if (!d.workspace || d.workspace_bytes < L.total * 4)
         return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
@@ -603,7 +624,6 @@ int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, h
         return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: the MEAN mode is forward-only (mode %d)", d.mode);
     if (d.mode == MOT_MIX_SUM && d.id_source != MOT_IDS_GIVEN)
         return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
-    if (d.ids_b && d.norm_byte) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: norm over two id tensors is not built");
     BwdArgs A;
     fill_bwd_args(A, d, gr);
     const size_t need = embed_mix_bwd_workspace_bytes(d);

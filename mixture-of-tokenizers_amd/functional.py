@@ -419,8 +419,6 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
         if tok_table.dtype != torch.float32:
             raise RuntimeError("mixture-of-tokenizers_amd: the backward is built for float32 tables only; "
                                "use torch.no_grad() with bfloat16 tables")
-        if kw.get("norm_byte") and (kw.get("ids_b") is not None or kw.get("add_padded")):
-            raise RuntimeError("mixture-of-tokenizers_amd: backward of norm(emb(padded) + emb(pulled)) is not built yet")
         r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"), tokens, kw)
         if kw.get("return_ids"):
             return MixResult(*r)

@@ -82,14 +82,15 @@ def test_noop_backward_vs_reference_autograd(mot):
 SCALED_SMALL = ("small", 97, 32, 8, 64, 8, 2, 16, 401)
 
 
-@pytest.mark.parametrize("mode", ["padded", "pulled"])
+@pytest.mark.parametrize("mode", ["padded", "pulled", "padded_and_pulled"])
 def test_concat_backward_vs_reference_autograd(mot, mode):
     """loss.backward() through FlexibleEmbedding + ByteMixin(concat) (train_gpt.py:605-606, 1319) against the
     gradients autograd produced for the reference modules: embed tables, mixin weight."""
     from mixture_of_tokenizers_amd import modules as M
     name, Vt, Dt, Db, Dm, bpt, B, T, seed = SCALED_SMALL
     z, zf = np.load(G / "grads.npz"), np.load(G / "float_scaled.npz")
-    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=mode == "pulled")
+    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=mode != "padded",
+                               add_padded_and_pulled=mode == "padded_and_pulled")
     dims = M.ModelDims(model_dim=Dm, byte_dim=Db, token_dim=Dt)
     embed, mixin = M.FlexibleEmbedding(dims, Vt, bp).to(DEV), M.ByteMixin(dims, T, bp).to(DEV)
     with torch.no_grad():
@@ -102,20 +103,6 @@ def test_concat_backward_vs_reference_autograd(mot, mode):
     assert rel(host(embed.embed_tokens.weight.grad), z[f"scaled/{mode}/f64/d_tok"]) < TOL
     assert rel(host(embed.embed_bytes.weight.grad), z[f"scaled/{mode}/f64/d_byte"]) < TOL
     assert rel(host(mixin.mixin.mixin.weight.grad), z[f"scaled/{mode}/f64/d_W"]) < TOL
-
-
-def test_concat_backward_unbuilt_combination_is_refused(mot):
-    """norm(emb(padded) + emb(pulled)) (add_padded_and_pulled) has no backward yet: it must say so."""
-    from mixture_of_tokenizers_amd import modules as M
-    bp = M.ByteHyperparameters(bytes_per_token=8, byte_mixin_method="concat", pull_in=True, add_padded_and_pulled=True)
-    dims = M.ModelDims(model_dim=64, byte_dim=8, token_dim=32)
-    embed, mixin = M.FlexibleEmbedding(dims, 97, bp).to(DEV), M.ByteMixin(dims, 16, bp).to(DEV)
-    toks = torch.zeros((1, 4), dtype=torch.int32, device=DEV)
-    ids = torch.zeros((1, 32), dtype=torch.int64, device=DEV)
-    with pytest.raises(RuntimeError, match="not built"):
-        mixin(*embed(toks, ids, ids))
-    with torch.no_grad():
-        assert mixin(*embed(toks, ids, ids)).shape == (1, 4, 64)
 
 
 def test_mathblations_backward_vs_reference_autograd(mot):
@@ -146,10 +133,13 @@ def test_mathblations_backward_vs_reference_autograd(mot):
     (128, 32, 8, 200, 512, 2, 77, dict(norm_tok=True, bias=True), 9203),                            # ragged Dm, bias, no out norm
     (256, 256, 3, 256, 1003, 8, 32, dict(bias=True, bytes_first=True), 9204),                       # mathblations dims
     (100, 20, 5, 384, 512, 2, 130, dict(norm_byte=True, norm_out=True, bytes_first=True, scaled=True), 9205),
+    (256, 48, 16, 1024, 2048, 2, 160, dict(norm_tok=True, norm_byte=True, norm_out=True, dual=True), 9206),  # norm(emb(padded)+emb(pulled))
+    (64, 24, 7, 96, 300, 3, 50, dict(norm_byte=True, dual=True, scaled=True, bias=True), 9207),               # ragged slots across lanes
+    (128, 32, 8, 256, 512, 2, 90, dict(norm_tok=True, dual=True), 9208),                                    # two id tensors, no byte norm
 ])
 def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     kw = dict(kw)
-    scaled, use_bias = kw.pop("scaled", False), kw.pop("bias", False)
+    scaled, use_bias, dual = kw.pop("scaled", False), kw.pop("bias", False), kw.pop("dual", False)
     tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=min(4.4, bpt / 2))
     toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
     Et, Eb = f32(gi.normal_table(seed + 2, Vt, Dt)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
@@ -157,7 +147,8 @@ def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     W = f32(gi.casted_linear_weight(seed + 4, Dm, K))
     bias = f32(gi.linear_weight_bias(seed + 5, Dm, K)[1]) if use_bias else None
     g = f32(np.random.RandomState(seed + 6).standard_normal((B, T, Dm)))
-    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    padded = orc.tokens_to_bytes(toks, tab.astype(np.float32))
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
     okw = dict(kw)
     dEt, dEb, dW = (torch.nn.Parameter(dev(a)) for a in (Et, Eb, W))
     dbias = torch.nn.Parameter(dev(bias)) if use_bias else None
@@ -166,7 +157,9 @@ def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
         okw.update(scale_tok=1.3, scale_byte=0.6)
         st, sb = torch.nn.Parameter(torch.tensor([1.3], device=DEV)), torch.nn.Parameter(torch.tensor([0.6], device=DEV))
         gkw.update(scale_tok=st, scale_byte=sb)
-    ref = orc.embed_mix_bwd(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
+    if dual:
+        gkw.update(add_padded=True)
+    ref = orc.embed_mix_bwd(toks, pulled, padded if dual else None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
                             mode="concat_linear", bpt=bpt, weight=W.astype(np.float64),
                             bias=None if bias is None else bias.astype(np.float64), dtype=np.float64, **okw)
     x = mot.embed_mix(dev(toks), dEt, dEb, mode="concat_linear", bpt=bpt, ttb=dev(tab), pull="left", weight=dW, bias=dbias, **gkw)
