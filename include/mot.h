@@ -201,7 +201,10 @@ typedef struct MotEmbedMixDesc {
  * `fwd` is the forward's descriptor with id_source == MOT_IDS_GIVEN (pass the byte ids the forward
  * returned through out_ids_*); `out`, `out_ids_*`, `counters` are ignored.  Gradients are ACCUMULATED
  * (+=) into the given buffers, so a parameter's .grad can be passed directly; NULL = not wanted.
- * Built: MOT_MIX_SUM, MOT_MIX_NOOP and MOT_MIX_CONCAT_LINEAR (fp32; MEAN returns MOT_EUNSUPPORTED).
+ * Built: MOT_MIX_SUM, MOT_MIX_NOOP and MOT_MIX_CONCAT_LINEAR (MEAN returns MOT_EUNSUPPORTED).
+ * With dtype == MOT_BF16 the tables, weight/bias, `out` and grad_out are bf16 as in the forward, while
+ * every gradient buffer below stays FP32 (sums of thousands of terms are accumulated in fp32; the
+ * caller rounds once when it needs a bf16 .grad, train_gpt.py:1124-1126).
  * CONCAT_LINEAR additionally needs `out` (the forward's x) and, when norm_out, `out_row_rnorm` of the
  * forward in `fwd`, and a workspace of mot_embed_mix_bwd_workspace_bytes(fwd).
  * Sums use float atomics: results are order-dependent in the last bits, like the reference's own
@@ -211,10 +214,10 @@ typedef struct MotEmbedMixGrads {
     uint32_t struct_size;  /* sizeof(MotEmbedMixGrads) */
     uint32_t reserved;
     const void *grad_out;  /* [B, T, model_dim] upstream gradient dL/dx */
-    void *d_tok_table;     /* [tok_rows, tok_dim]   */
-    void *d_byte_table;    /* [byte_rows, byte_dim] */
-    void *d_weight;        /* [model_dim, K]   (CONCAT_LINEAR) */
-    void *d_bias;          /* [model_dim]      (CONCAT_LINEAR with bias; optional) */
+    void *d_tok_table;     /* [tok_rows, tok_dim]   fp32 */
+    void *d_byte_table;    /* [byte_rows, byte_dim] fp32 */
+    void *d_weight;        /* [model_dim, K]   fp32 (CONCAT_LINEAR) */
+    void *d_bias;          /* [model_dim]      fp32 (CONCAT_LINEAR with bias; optional) */
     float *d_scale_tok;    /* scalar */
     float *d_scale_byte;   /* scalar */
 } MotEmbedMixGrads;

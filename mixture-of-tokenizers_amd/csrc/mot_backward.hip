@@ -57,8 +57,14 @@ struct BwdArgs {
     int Dt, tok_lo, byte_lo, nbk;
     int privatize;  // byte-table gradient accumulated in LDS
     const int32_t *pos_sorted;  // token positions ordered by token id
+    int in_bf16;  // tables and grad_out are bf16 (gradients are accumulated and returned in fp32 either way)
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
 };
+
+// element i of a float or bf16 array (uniform choice per launch)
+__device__ __forceinline__ float ld_in(const float *base, int64_t i, int bf16) {
+    return bf16 ? (float)((const __bf16 *)base)[i] : base[i];
+}
 
 template <int MODE, int NE>
 __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArgs A) {
@@ -140,24 +146,23 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
 #pragma unroll
             for (int j = 0; j < NE; ++j) acc[j] = 0.f;
         }
-        const float *trow = A.tok_table + (int64_t)tok * Dt;
-        const float *grow = A.grad_out + n * D;
+        const int64_t trow = (int64_t)tok * Dt, grow = n * D;
         float an[NE], bn[NE], dy[NE];
         // ---- gather (the same rows the forward read)
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int e = lane + 64 * j;
             const int et = tok_off(e), eb = byte_off(e);
-            an[j] = et >= 0 ? trow[et] : 0.f;
-            dy[j] = e < D ? grow[e] : 0.f;  // holds g until the norm backward below
+            an[j] = et >= 0 ? ld_in(A.tok_table, trow + et, A.in_bf16) : 0.f;
+            dy[j] = e < D ? ld_in(A.grad_out, grow + e, A.in_bf16) : 0.f;  // holds g until the norm backward below
             bn[j] = 0.f;
             if (eb >= 0) {
                 const int sl = slot_of(eb), wi = eb - sl * A.Db;
-                float v = A.byte_table[(int64_t)id1[j] * A.Db + wi];
+                float v = ld_in(A.byte_table, (int64_t)id1[j] * A.Db + wi, A.in_bf16);
                 if (A.ids_b) {
                     int64_t ib = A.ids_b[n * A.bpt + sl];
                     if ((uint64_t)ib >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); ib = 0; }
-                    v += A.byte_table[ib * A.Db + wi];
+                    v += ld_in(A.byte_table, ib * A.Db + wi, A.in_bf16);
                 }
                 if (A.norm_byte && !pair_norm) v *= A.byte_rnorm[id1[j]];
                 bn[j] = v;  // normalised, unscaled
@@ -374,7 +379,7 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
         const size_t tab = (size_t)d.byte_rows * d.byte_dim * sizeof(float);
         if (tab + lds <= 150 * 1024) { A.privatize = 1; lds += tab; }
         if (d.norm_byte && !(MODE == MOT_MIX_CONCAT_LINEAR && d.ids_b)) {
-            rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rnorm_ws, MOT_F32, stream);
+            rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rnorm_ws, A.in_bf16 ? MOT_BF16 : MOT_F32, stream);
             if (rc) return rc;
             A.byte_rnorm = rnorm_ws;
         }
@@ -388,7 +393,8 @@ static void fill_bwd_args(BwdArgs &A, const MotEmbedMixDesc &d, const MotEmbedMi
     A.tok_table = (const float *)d.tok_table; A.tok_rows = d.tok_rows; A.D = d.tok_dim;
     A.byte_table = (const float *)d.byte_table; A.byte_rows = d.byte_rows; A.Db = d.byte_dim;
     A.norm_tok = d.norm_tok; A.norm_byte = d.norm_byte; A.norm_out = d.norm_out;
-    A.eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    A.in_bf16 = d.dtype == MOT_BF16;
+    A.eps = d.eps > 0.f ? d.eps : (A.in_bf16 ? kBf16Eps : FLT_EPSILON);
     A.scale_tok = d.scale_tok; A.scale_byte = d.scale_byte; A.byte_rnorm = nullptr;
     A.grad_out = (const float *)gr.grad_out;
     A.d_tok = (float *)gr.d_tok_table; A.d_byte = (float *)gr.d_byte_table;
@@ -549,11 +555,45 @@ static LinBwdLayout lin_bwd_layout(const MotEmbedMixDesc &d) {
     return L;
 }
 
+// bf16 CONCAT_LINEAR backward: the operands are widened once into fp32 workspace copies and the fp32 pipeline
+// above runs on them (fp32 MFMA and fp32 accumulation throughout -- never less precise than bf16 autograd;
+// the bf16-MFMA version of the three GEMMs is the open item).  Layout in floats, in front of LinBwdLayout.
+struct UpLayout { size_t tok, byte, w, bias, g, x, total; };
+static UpLayout up_layout(const MotEmbedMixDesc &d) {
+    UpLayout U;
+    const size_t N = (size_t)(d.n_rows * d.tokens_per_row), K = (size_t)d.tok_dim + (size_t)d.bpt * d.byte_dim;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 3) & ~(size_t)3; return at; };
+    U.tok = take((size_t)d.tok_rows * d.tok_dim); U.byte = take((size_t)d.byte_rows * d.byte_dim); U.w = take((size_t)d.model_dim * K);
+    U.bias = take(d.bias ? d.model_dim : 0); U.g = take(N * d.model_dim); U.x = take(d.norm_out ? N * d.model_dim : 0);
+    U.total = o;
+    return U;
+}
+
+__global__ __launch_bounds__(kThreads) void widen_kernel(const __bf16 *__restrict__ src, int64_t n, float *__restrict__ dst) {
+    for (int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * kThreads * 8) {
+        if (i + 8 <= n && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0) {
+            const float8v v = Elem<__bf16>::loadv(src + i);
+            *(float4v *)(dst + i) = __builtin_shufflevector(v, v, 0, 1, 2, 3);
+            *(float4v *)(dst + i + 4) = __builtin_shufflevector(v, v, 4, 5, 6, 7);
+        } else {
+            for (int64_t j = i; j < min(n, i + 8); ++j) dst[j] = (float)src[j];
+        }
+    }
+}
+static int launch_widen(const void *src, size_t n, float *dst, hipStream_t stream) {
+    if (!n) return MOT_OK;
+    size_t blocks = (n / 8 + kThreads) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, (const __bf16 *)src, (int64_t)n, dst);
+    return check_launch("widen_kernel");
+}
+
 static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
     if (d.mode == MOT_MIX_CONCAT_LINEAR) {
         // the du GEMM runs through launch_embed_mix_linear_ex with its own (small) scratch after ours
-        return lin_bwd_layout(d).total * 4 + 64;
+        return (lin_bwd_layout(d).total + (d.dtype == MOT_BF16 ? up_layout(d).total : 0)) * 4 + 64;
     }
     return (bwd_rnorm_floats(d) + scatter_ws_ints(d)) * 4;
 }
@@ -566,6 +606,29 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     const int Dm = d.model_dim, Dt = d.tok_dim, nbk = d.bpt * d.byte_dim, K = Dt + nbk;
     if (K > 1024 || Dm > 2048) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 or model_dim %d > 2048", K, Dm);
     const LinBwdLayout L = lin_bwd_layout(d);
+    if (d.dtype == MOT_BF16) {
+        const UpLayout U = up_layout(d);
+        if (!d.workspace || d.workspace_bytes < (U.total + L.total) * 4)
+            return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", (U.total + L.total) * 4, d.workspace_bytes);
+        float *up = (float *)d.workspace;
+        const size_t Nn = (size_t)N * Dm;
+        int rc;
+        if ((rc = launch_widen(d.tok_table, (size_t)d.tok_rows * Dt, up + U.tok, stream))) return rc;
+        if ((rc = launch_widen(d.byte_table, (size_t)d.byte_rows * d.byte_dim, up + U.byte, stream))) return rc;
+        if ((rc = launch_widen(d.weight, (size_t)Dm * K, up + U.w, stream))) return rc;
+        if (d.bias && (rc = launch_widen(d.bias, Dm, up + U.bias, stream))) return rc;
+        if ((rc = launch_widen(gr.grad_out, Nn, up + U.g, stream))) return rc;
+        if (d.norm_out && (rc = launch_widen(d.out, Nn, up + U.x, stream))) return rc;
+        MotEmbedMixDesc d32 = d;
+        MotEmbedMixGrads g32 = gr;
+        d32.dtype = MOT_F32;
+        d32.tok_table = up + U.tok; d32.byte_table = up + U.byte; d32.weight = up + U.w; d32.bias = d.bias ? up + U.bias : nullptr;
+        d32.out = d.norm_out ? (void *)(up + U.x) : nullptr;
+        d32.eps = d.eps > 0.f ? d.eps : kBf16Eps;   // the forward normalised with the bf16 epsilon
+        d32.workspace = up + U.total; d32.workspace_bytes = d.workspace_bytes - U.total * 4;
+        g32.grad_out = up + U.g;
+        return launch_embed_mix_bwd_linear(d32, g32, stream);
+    }
     if (!d.workspace || d.workspace_bytes < L.total * 4)
         return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
     float *ws = (float *)d.workspace;

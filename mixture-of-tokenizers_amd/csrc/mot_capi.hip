@@ -173,7 +173,6 @@ int mot_embed_mix_bwd(const MotEmbedMixDesc *desc, const MotEmbedMixGrads *grads
     if (!d.out) d.out = (void *)grads->grad_out;  // the forward validator wants a non-null `out` (only CONCAT_LINEAR reads it)
     int rc = validate_embed_mix(&d);
     if (rc) return rc;
-    if (d.dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: only MOT_F32 is built");
     if (!grads->grad_out) return set_error(MOT_EINVAL, "embed_mix_bwd: grad_out missing");
     if (!grads->d_tok_table) return set_error(MOT_EINVAL, "embed_mix_bwd: d_tok_table missing");
     if (d.mode == MOT_MIX_SUM && !grads->d_byte_table) return set_error(MOT_EINVAL, "embed_mix_bwd: d_byte_table missing");

@@ -32,6 +32,7 @@ struct LinArgs16 {
     const __bf16 *W;     // [Dm, K] nn.Linear layout
     const __bf16 *bias;  // [Dm] or null
     int K, Dm, bytes_first, dual;
+    float *row_rnorm;    // optional [n_rows*T]: the post-norm factor of every row (for the backward)
 };
 
 __host__ __device__ inline size_t lin16_lds_bytes(int DmPad, int bpt, int tm) {
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
                 const float rs = rms_scale(tot, P.Dm, A.eps);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] *= rs;
+                if (P.row_rnorm && wave == 0 && li == 0 && m < ntok) P.row_rnorm[row * A.T + t0 + m] = rs;
             }
     }
     __bf16 *orow = (__bf16 *)A.out + (row * A.T + t0) * (int64_t)P.Dm;
@@ -297,6 +299,7 @@ int launch_embed_mix_linear_bf16(const MotEmbedMixDesc &d, hipStream_t stream) {
     P.dual = d.id_source == MOT_IDS_FROM_TTB ? d.add_padded != 0 : d.ids_b != nullptr;
     P.W = (const __bf16 *)d.weight;
     P.bias = (const __bf16 *)d.bias;
+    P.row_rnorm = d.norm_out ? d.out_row_rnorm : nullptr;
     if (d.norm_byte && !P.dual) {
         const size_t need = (size_t)d.byte_rows * sizeof(float);
         if (!d.workspace || d.workspace_bytes < need)

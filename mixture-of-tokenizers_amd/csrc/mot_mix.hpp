@@ -73,6 +73,8 @@ struct MixArgs {
     int tile_tokens, tiles_per_row;
 };
 
+constexpr float kBf16Eps = 0.0078125f;  // torch.finfo(torch.bfloat16).eps: what F.rms_norm(eps=None) uses on bf16 input
+
 __device__ __forceinline__ float rms_scale(float sumsq, int dim, float eps) {
     // F.rms_norm: x * rsqrt(mean(x^2) + eps)   (train_gpt.py:172-173)
     return 1.0f / sqrtf(sumsq / (float)dim + eps);
@@ -171,7 +173,7 @@ inline void fill_mix_args(MixArgs &A, const MotEmbedMixDesc &d) {
     A.byte_table = (const float *)d.byte_table; A.byte_rows = d.byte_rows; A.Db = d.byte_dim;
     A.norm_tok = d.norm_tok; A.norm_byte = d.norm_byte; A.norm_out = d.norm_out;
     // F.rms_norm(eps=None) uses torch.finfo(x.dtype).eps: 2^-23 for fp32 inputs, 2^-7 for bf16 inputs
-    A.eps = d.eps > 0.f ? d.eps : (d.dtype == MOT_BF16 ? 0.0078125f : FLT_EPSILON);
+    A.eps = d.eps > 0.f ? d.eps : (d.dtype == MOT_BF16 ? kBf16Eps : FLT_EPSILON);
     A.scale_tok = d.scale_tok; A.scale_byte = d.scale_byte;
     A.byte_rnorm = nullptr;
     A.out = (float *)d.out;

@@ -159,6 +159,9 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     if tokens.ndim != 2:
         raise ValueError("tokens must be (B, T) or (T,)")
     dev = capi.require_device(tokens, tok_table, byte_table, ttb, ids_a, ids_b, weight, bias, scale_tok, scale_byte)
+    for what, sc in (("scale_tok", scale_tok), ("scale_byte", scale_byte)):
+        if sc is not None and (sc.dtype != torch.float32 or sc.numel() != 1):
+            raise TypeError(f"{what}: expected a 1-element float32 device tensor, got {sc.dtype} x {sc.numel()}")
     tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
     tok = tok if tok.is_contiguous() else tok.contiguous()
     B, T = tok.shape
@@ -314,10 +317,10 @@ class _EmbedMixFn(torch.autograd.Function):
                                scale_byte=None if scale_byte is None else scale_byte.detach(),
                                weight=None if weight is None else weight.detach(), bias=None if bias is None else bias.detach(),
                                out=None if x is None else x.detach(), row_rnorm=rn, **ctx.kw)
-        return (g["tok_table"], g["byte_table"],
-                None if scale_tok is None else g["scale_tok"].reshape(scale_tok.shape),
-                None if scale_byte is None else g["scale_byte"].reshape(scale_byte.shape),
-                g.get("weight"), g.get("bias"), None, None)
+        def like(t, p):  # bf16 parameters get their gradient rounded once, from the fp32 sums
+            return None if t is None or p is None else t.to(p.dtype).reshape(p.shape)
+        return (like(g["tok_table"], tok_table), like(g.get("byte_table"), byte_table), like(g.get("scale_tok"), scale_tok),
+                like(g.get("scale_byte"), scale_byte), like(g.get("weight"), weight), like(g.get("bias"), bias), None, None)
 
 
 @torch.compiler.disable
@@ -329,7 +332,9 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
                        out: torch.Tensor | None = None, row_rnorm: torch.Tensor | None = None,
                        into: dict | None = None) -> dict:
     """One launch of mot_embed_mix_bwd.  Returns dense fp32 gradients {tok_table, byte_table, scale_tok,
-    scale_byte}; pass `into` (same keys) to accumulate into existing buffers such as ``param.grad``."""
+    scale_byte, weight, bias} -- fp32 also when the tables are bfloat16 (accumulated in fp32; the autograd
+    node rounds once to the parameter dtype); pass `into` (same keys, fp32) to accumulate into existing
+    buffers such as ``param.grad``."""
     m = _MODES[mode]
     if tokens.ndim == 1:
         tokens = tokens[None]
@@ -337,11 +342,13 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
     tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
     tok = tok if tok.is_contiguous() else tok.contiguous()
     B, T = tok.shape
-    tt = _contig(tok_table, torch.float32, "tok_table")
-    g = _contig(grad_out, torch.float32, "grad_out")
+    dt = tok_table.dtype
+    code = capi.dtype_code(dt)
+    tt = _contig(tok_table, dt, "tok_table")
+    g = _contig(grad_out, dt, "grad_out")
     d = capi.MotEmbedMixDesc()
     d.struct_size = C.sizeof(capi.MotEmbedMixDesc)
-    d.dtype = capi.F32
+    d.dtype = code
     d.n_rows, d.tokens_per_row, d.bpt, d.mode = B, T, int(bpt), m
     d.tokens = capi.ptr(tok)
     d.tok_table, d.tok_rows, d.tok_dim, d.model_dim = capi.ptr(tt), tt.shape[0], tt.shape[1], tt.shape[1]
@@ -350,14 +357,14 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
     out = {"tok_table": into.get("tok_table", None), "byte_table": into.get("byte_table", None),
            "scale_tok": into.get("scale_tok", None), "scale_byte": into.get("scale_byte", None)}
     if out["tok_table"] is None:
-        out["tok_table"] = torch.zeros_like(tt)
+        out["tok_table"] = torch.zeros_like(tt, dtype=torch.float32)
     keep = [tok, tt, g]
     gr = capi.MotEmbedMixGrads()
     gr.struct_size = C.sizeof(capi.MotEmbedMixGrads)
     gr.grad_out = capi.ptr(g)
     gr.d_tok_table = capi.ptr(out["tok_table"])
     if m != capi.MIX_NOOP:
-        bt = _contig(byte_table, torch.float32, "byte_table")
+        bt = _contig(byte_table, dt, "byte_table")
         ia = _contig(ids_a, torch.int64, "ids_a")
         keep += [bt, ia]
         d.byte_table, d.byte_rows, d.byte_dim = capi.ptr(bt), bt.shape[0], bt.shape[1]
@@ -367,24 +374,24 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
             keep.append(ib)
             d.ids_b = capi.ptr(ib)
         if out["byte_table"] is None:
-            out["byte_table"] = torch.zeros_like(bt)
+            out["byte_table"] = torch.zeros_like(bt, dtype=torch.float32)
         gr.d_byte_table = capi.ptr(out["byte_table"])
     if m == capi.MIX_CONCAT_LINEAR:
-        w = _contig(weight, torch.float32, "weight")
+        w = _contig(weight, dt, "weight")
         keep.append(w)
         d.weight, d.model_dim, d.bytes_first = capi.ptr(w), w.shape[0], int(bytes_first)
-        out["weight"] = into.get("weight") if into.get("weight") is not None else torch.zeros_like(w)
+        out["weight"] = into.get("weight") if into.get("weight") is not None else torch.zeros_like(w, dtype=torch.float32)
         gr.d_weight = capi.ptr(out["weight"])
         if bias is not None:
-            bs = _contig(bias, torch.float32, "bias")
+            bs = _contig(bias, dt, "bias")
             keep.append(bs)
             d.bias = capi.ptr(bs)
-            out["bias"] = into.get("bias") if into.get("bias") is not None else torch.zeros_like(bs)
+            out["bias"] = into.get("bias") if into.get("bias") is not None else torch.zeros_like(bs, dtype=torch.float32)
             gr.d_bias = capi.ptr(out["bias"])
         if norm_out:
             if fwd_out is None or row_rnorm is None:
                 raise ValueError("concat_linear backward with norm_out needs the forward's output and row_rnorm")
-            xo = _contig(fwd_out, torch.float32, "out")
+            xo = _contig(fwd_out, dt, "out")
             keep.append(xo)
             d.out, d.out_row_rnorm = capi.ptr(xo), capi.ptr(row_rnorm)
     d.norm_tok, d.norm_byte, d.norm_out = int(norm_tok), int(norm_byte), int(norm_out)
@@ -407,7 +414,7 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
               scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None, **kw):
     """The fused front-end (see `_embed_mix_fwd` for the arguments).  With autograd enabled and
     differentiable parameters it records one backward node (modes "sum", "noop", "concat_linear";
-    fp32 tables)."""
+    float32 or bfloat16 tables)."""
     params = (tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"))
     if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
         if kw["mode"] not in _BWD_MODES:
@@ -416,9 +423,6 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
                 "call it under torch.no_grad() or with frozen parameters")
         if kw.get("out") is not None or kw.get("counters") is not None:
             raise ValueError("out= / counters= cannot be combined with autograd")
-        if tok_table.dtype != torch.float32:
-            raise RuntimeError("mixture-of-tokenizers_amd: the backward is built for float32 tables only; "
-                               "use torch.no_grad() with bfloat16 tables")
         r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"), tokens, kw)
         if kw.get("return_ids"):
             return MixResult(*r)

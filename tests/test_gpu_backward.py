@@ -212,3 +212,28 @@ def test_sum_backward_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
         got2 = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(pulled),
                                                  ids_b=dev(padded), **gkw)
         assert rel(host(got2["byte_table"]), ref2["byte_table"]) < TOL
+
+
+def test_grad_bucket_accumulates_in_place(mot):
+    """GradBucket (grad_sync.py): the front-end's .grad tensors are views of one flat buffer, autograd adds into
+    them in place, and two micro-batches accumulate to the gradient of their union (train_gpt.py:1319-1321)."""
+    from mixture_of_tokenizers_amd.grad_sync import GradBucket
+    from mixture_of_tokenizers_amd.modules import SumFrontEnd
+    Vt, D, Db, bpt, B, T = 512, 128, 16, 8, 4, 96
+    tab = gi.synth_ttb(9301, Vt, bpt, "left")
+    toks = gi.fineweb_like_tokens(9300, B, T, vocab=Vt, eot_p=0.02)
+    g = f32(np.random.RandomState(9302).standard_normal((B, T, D)))
+    fe = SumFrontEnd(Vt, gi.BYTE_VOCAB, D, Db, bpt, variant="71041", ttb=dev(tab)).to(DEV)
+    params = list(fe.parameters())
+    bucket = GradBucket(params)
+    ptrs = [p.grad.data_ptr() for p in bucket.params]
+    for rows in (slice(0, 2), slice(2, 4)):
+        (fe(dev(toks[rows])) * dev(g[rows])).sum().backward()
+    assert [p.grad.data_ptr() for p in bucket.params] == ptrs
+    assert bucket.all_reduce() is None                      # no process group: nothing to exchange
+    acc = [p.grad.clone() for p in bucket.params]
+    bucket.zero_()
+    assert all(float(p.grad.abs().max()) == 0.0 for p in bucket.params)
+    (fe(dev(toks)) * dev(g)).sum().backward()
+    for a, p in zip(acc, bucket.params):
+        assert rel(host(a), host(p.grad)) < TOL

@@ -158,3 +158,109 @@ def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
     with torch.no_grad():
         x = mixin(*embed(toks, ids, ids))
     assert x.dtype == torch.bfloat16 and x.shape == (B, T, Dm) and bool(torch.isfinite(x.float()).all())
+
+
+# ------------------------------------------------------------------------------------------------
+# backward with bf16 tables (what loss.backward() runs in production, train_gpt.py:1124-1126, 1319).
+# The kernels read bf16 operands, accumulate in fp32 and hand fp32 sums to the autograd node, which rounds
+# once to the parameter dtype.  Oracle: float64 backward on the same bf16-valued operands with eps = 2^-7.
+#   * fp32 sums (embed_mix_backward called directly), SUM/NOOP: same bar as the fp32 backward, 2e-5 of max|ref|;
+#   * CONCAT_LINEAR: the saved forward output x is bf16 (2^-9 relative per element) and enters dy, so 2e-3;
+#   * .grad on bf16 parameters: additionally one bf16 rounding of each element (2^-8 relative).
+# ------------------------------------------------------------------------------------------------
+def relmax(got, ref):
+    ref = np.asarray(ref, dtype=np.float64)
+    return np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+
+
+@pytest.mark.parametrize("D,Db,bpt,Vt,B,T,kw,seed", [
+    (768, 48, 16, 4096, 4, 512, dict(norm_out=True), 9701),                                          # headline dims
+    (768, 48, 16, 4096, 2, 300, dict(norm_tok=True, norm_byte=True, norm_out=True, scaled=True), 9702),
+    (480, 24, 20, 300, 2, 100, dict(norm_out=True), 9703),                                           # D % 64 != 0
+])
+def test_bf16_sum_backward_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
+    kw = dict(kw)
+    scaled = kw.pop("scaled", False)
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left")
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = orc.bf16_round(gi.normal_table(seed + 2, Vt, D)), orc.bf16_round(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    g = orc.bf16_round(np.random.RandomState(seed + 4).standard_normal((B, T, D)))
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    okw, gkw = dict(kw), dict(kw)
+    if scaled:
+        okw.update(scale_tok=1.3, scale_byte=0.6)
+        gkw.update(scale_tok=torch.tensor([1.3], device=DEV), scale_byte=torch.tensor([0.6], device=DEV))
+    orc.set_eps(2.0 ** -7)
+    try:
+        ref = orc.embed_mix_bwd(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
+                                mode="sum", bpt=bpt, dtype=np.float64, **okw)
+    finally:
+        orc.set_eps(0.0)
+    got = mot.functional.embed_mix_backward(dev(g).bfloat16(), dev(toks), dev(Et).bfloat16(), dev(Eb).bfloat16(), mode="sum", bpt=bpt,
+                                            ids_a=dev(pulled), **gkw)
+    assert got["tok_table"].dtype == torch.float32
+    assert relmax(host(got["tok_table"]), ref["tok_table"]) < 2e-5
+    assert relmax(host(got["byte_table"]), ref["byte_table"]) < 2e-5
+    if scaled:
+        assert abs(float(got["scale_tok"]) - ref["scales"][0]) < 2e-5 * abs(ref["scales"]).max()
+        assert abs(float(got["scale_byte"]) - ref["scales"][1]) < 2e-5 * abs(ref["scales"]).max()
+
+
+@pytest.mark.parametrize("Dt,Db,bpt,Dm,Vt,B,T,kw,seed", [
+    (256, 32, 16, 768, 4096, 2, 512, dict(norm_tok=True, norm_byte=True, norm_out=True), 9801),     # C2-CONCAT dims
+    (256, 256, 3, 256, 1003, 8, 32, dict(bias=True, bytes_first=True), 9802),                       # mathblations dims
+    (256, 48, 16, 1024, 2048, 2, 160, dict(norm_tok=True, norm_byte=True, norm_out=True, dual=True), 9803),
+])
+def test_bf16_concat_backward_through_autograd(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
+    kw = dict(kw)
+    use_bias, dual = kw.pop("bias", False), kw.pop("dual", False)
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=min(4.4, bpt / 2))
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = orc.bf16_round(gi.normal_table(seed + 2, Vt, Dt)), orc.bf16_round(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    K = Dt + bpt * Db
+    W = orc.bf16_round(gi.casted_linear_weight(seed + 4, Dm, K))
+    bias = orc.bf16_round(gi.linear_weight_bias(seed + 5, Dm, K)[1]) if use_bias else None
+    g = orc.bf16_round(np.random.RandomState(seed + 6).standard_normal((B, T, Dm)))
+    padded = orc.tokens_to_bytes(toks, tab.astype(np.float32))
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    orc.set_eps(2.0 ** -7)
+    try:
+        ref = orc.embed_mix_bwd(toks, pulled, padded if dual else None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
+                                mode="concat_linear", bpt=bpt, weight=W.astype(np.float64),
+                                bias=None if bias is None else bias.astype(np.float64), dtype=np.float64, **kw)
+    finally:
+        orc.set_eps(0.0)
+    P = lambda a: None if a is None else torch.nn.Parameter(dev(a).bfloat16())
+    pEt, pEb, pW, pb = P(Et), P(Eb), P(W), P(bias)
+    x = mot.embed_mix(dev(toks), pEt, pEb, mode="concat_linear", bpt=bpt, ttb=dev(tab), pull="left", weight=pW, bias=pb,
+                      add_padded=dual, **kw)
+    assert x.dtype == torch.bfloat16 and x.requires_grad
+    (x.float() * dev(g)).sum().backward()
+    for p, name in ((pEt, "tok_table"), (pEb, "byte_table"), (pW, "weight"), (pb, "bias")):
+        if p is None:
+            continue
+        assert p.grad.dtype == torch.bfloat16
+        r = np.asarray(ref[name], dtype=np.float64)
+        err = np.abs(host(p.grad.float()).astype(np.float64) - r)
+        assert (err <= 2.0 ** -8 * np.abs(r) + 2e-3 * np.abs(r).max()).all(), name
+
+
+def test_bf16_training_step_through_modules(mot):
+    """bf16 nn.Embedding tables + fp32 CastedLinear master weight (train_gpt.py:1124-1126, 185-186) under
+    loss.backward(): bf16 table gradients, fp32 weight gradient, all finite and non-trivial."""
+    from mixture_of_tokenizers_amd import modules as M
+    Vt, Dt, Db, Dm, bpt, B, T = 512, 64, 16, 128, 8, 2, 64
+    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=True)
+    dims = M.ModelDims(model_dim=Dm, byte_dim=Db, token_dim=Dt)
+    embed, mixin = M.FlexibleEmbedding(dims, Vt, bp).to(DEV), M.ByteMixin(dims, T, bp).to(DEV)
+    for m in embed.modules():
+        if isinstance(m, torch.nn.Embedding):
+            m.bfloat16()
+    toks = dev(gi.fineweb_like_tokens(1, B, T, vocab=Vt))
+    ids = torch.randint(0, gi.BYTE_VOCAB, (B, T * bpt), device=DEV)
+    x = mixin(*embed(toks, ids, ids))
+    (x.float() * torch.randn(x.shape, device=DEV)).sum().backward()
+    gt, gb, gw = embed.embed_tokens.weight.grad, embed.embed_bytes.weight.grad, mixin.mixin.mixin.weight.grad
+    assert gt.dtype == torch.bfloat16 and gb.dtype == torch.bfloat16 and gw.dtype == torch.float32
+    for t in (gt, gb, gw):
+        assert bool(torch.isfinite(t.float()).all()) and float(t.float().abs().max()) > 0

@@ -143,3 +143,53 @@ def test_world_size_2_gloo(tmp_path):
     np.testing.assert_array_equal(res["pulled"].numpy(), pulled)         # sharded == unsharded, bit for bit
     st = orc.byte_stats(padded, pulled, gi.PAD)
     assert res["counters"].tolist() == [toks.size, int(st[0]), int(st[1]), int(st[2])]
+
+
+# ---------------------------------------------------------------------------------------------
+# world_size 2 over gloo: the front-end's gradient exchange (train_gpt.py:1320-1321) through GradBucket.
+# Each rank's backward is the oracle's (CPU-only host); rank-averaged gradients must equal the
+# unsharded backward / world.
+# ---------------------------------------------------------------------------------------------
+def _grad_case():
+    bpt, Vt, D, Db, B, T = 8, 300, 64, 8, 4, 40
+    tab = gi.synth_ttb(5101, Vt, bpt, "left").astype(np.float32)
+    toks = gi.fineweb_like_tokens(5100, B, T, vocab=Vt, eot_p=0.02)
+    Et, Eb = gi.normal_table(5102, Vt, D), gi.normal_table(5103, gi.BYTE_VOCAB, Db)
+    g = np.random.RandomState(5104).standard_normal((B, T, D))
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab), bpt, gi.PAD, gi.EOT)
+    return bpt, toks, pulled, Et.astype(np.float64), Eb.astype(np.float64), g
+
+
+def _grad_worker(rank, world, port, tmp):
+    sys.path.insert(0, str(REPO)); sys.path.insert(0, str(REPO / "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mixture_of_tokenizers_amd.grad_sync import GradBucket
+    bpt, toks, pulled, Et, Eb, g = _grad_case()
+    rows = slice(rank * toks.shape[0] // world, (rank + 1) * toks.shape[0] // world)
+    tok_p, byte_p = torch.nn.Parameter(torch.from_numpy(Et)), torch.nn.Parameter(torch.from_numpy(Eb))
+    tied = tok_p                                                  # a tied weight shows up twice in parameters()
+    bucket = GradBucket([tok_p, byte_p, tied])
+    assert len(bucket.params) == 2 and tok_p.grad.data_ptr() == bucket.flat.data_ptr()
+    for step in range(2):                                         # the views survive zero_() and accumulate in place
+        bucket.zero_()
+        ref = orc.embed_mix_bwd(toks[rows], pulled[rows], None, Et, Eb, g[rows], mode="sum", bpt=bpt, norm_out=True, dtype=np.float64)
+        tok_p.grad += torch.from_numpy(ref["tok_table"])
+        byte_p.grad += torch.from_numpy(ref["byte_table"])
+        work = bucket.all_reduce(async_op=True)
+        work.wait()
+    if rank == 0:
+        torch.save(dict(tok=tok_p.grad.clone(), byte=byte_p.grad.clone()), tmp)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_world_size_2_gloo(tmp_path):
+    out = tmp_path / "g2.pt"
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_grad_worker, args=(2, port, str(out)), nprocs=2, join=True)
+    res = torch.load(out)
+    bpt, toks, pulled, Et, Eb, g = _grad_case()
+    ref = orc.embed_mix_bwd(toks, pulled, None, Et, Eb, g, mode="sum", bpt=bpt, norm_out=True, dtype=np.float64)
+    np.testing.assert_allclose(res["tok"].numpy(), ref["tok_table"] / 2, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(res["byte"].numpy(), ref["byte_table"] / 2, rtol=1e-12, atol=1e-12)
