@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 4
+#define MOT_ABI_VERSION 5
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -229,6 +229,55 @@ int mot_embed_mix_bwd(const MotEmbedMixDesc *fwd /* host */, const MotEmbedMixGr
 size_t mot_embed_mix_desc_size(void); /* sizeof(MotEmbedMixDesc) in this build, for bindings */
 size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc /* host */);
 int mot_embed_mix_fwd(const MotEmbedMixDesc *desc /* host */, mot_stream_t stream);
+
+/*
+ * Cross-attention byte mixin, forward: replaces ByteMixinCrossAttn.forward on FlexibleEmbedding's outputs
+ * (scaled-pre-train/train_gpt.py:446-464 -> CrossAttention.forward 271-300; embeddings 342-379).
+ * Each token attends to its own `bpt` byte embeddings: q = q_w xq, (k, v) = kv_w xkv, per-head rms-norm of q and
+ * k, RoPE with the position in each one's own sequence, v *= lambda, softmax(q.k / sqrt(hd)) over the bpt
+ * keys, out = proj_w y.  The reference asserts batch 1 (line 275): tokens is one row of n_tokens.
+ * head_dim is 128 (line 459); dim = token_dim = byte_dim = model_dim (line 449).  fp32, forward only.
+ * head_layout MOT_HEADS_AS_VIEWED reproduces lines 283-284 (k, v are reshaped, not transposed, into
+ * (H, T, bpt, hd)); MOT_HEADS_PER_TOKEN is the einops expression in the comment of those lines.
+ * cos/sin are the Rotary buffers of the module (lines 190-197), fp32 [len, 64], built by the caller.
+ */
+typedef enum MotHeadLayout { MOT_HEADS_AS_VIEWED = 0, MOT_HEADS_PER_TOKEN = 1 } MotHeadLayout;
+
+typedef struct MotCrossAttnDesc {
+    uint32_t struct_size;     /* sizeof(MotCrossAttnDesc) */
+    int32_t dtype;            /* MOT_F32 */
+    int64_t n_tokens;         /* Tq; Tkv = n_tokens * bpt */
+    int32_t bpt;              /* chars_per_token, line 282 */
+    int32_t n_heads;          /* hdim = n_heads * 128 */
+    int32_t head_layout;      /* MotHeadLayout */
+    int32_t dim;              /* columns of both tables */
+    const int32_t *tokens;    /* [n_tokens] */
+    const int64_t *ids_a;     /* [n_tokens * bpt] byte ids */
+    const int64_t *ids_b;     /* optional second id tensor: xkv = norm?(E[a] + E[b]), line 378 */
+    const void *tok_table;    /* [tok_rows, dim] */
+    int64_t tok_rows;
+    const void *byte_table;   /* [byte_rows, dim] */
+    int64_t byte_rows;
+    int32_t norm_tok;         /* FlexibleEmbedding applies norm() to both (lines 367-378) */
+    int32_t norm_byte;
+    const void *q_w;          /* [hdim, dim]    CrossAttention.q_w */
+    const void *kv_w;         /* [2, hdim, dim] CrossAttention.kv_w */
+    const void *proj_w;       /* [dim, hdim]    CrossAttention.c_proj.weight */
+    const float *lambda_factor; /* device scalar */
+    const float *cos_q, *sin_q; /* [>= n_tokens, 64] */
+    const float *cos_k, *sin_k; /* [>= n_tokens * bpt, 64] */
+    int64_t rot_q_len, rot_k_len; /* rows of the two pairs of buffers (line 200 asserts they suffice) */
+    float eps;                /* 0 = finfo(float32).eps */
+    int32_t reserved;
+    void *out;                /* [n_tokens, dim] */
+    uint32_t *status;         /* optional, as in MotEmbedMixDesc */
+    void *workspace;          /* mot_cross_attn_workspace_bytes(desc) */
+    size_t workspace_bytes;
+} MotCrossAttnDesc;
+
+size_t mot_cross_attn_desc_size(void);
+size_t mot_cross_attn_workspace_bytes(const MotCrossAttnDesc *desc /* host */);
+int mot_cross_attn_fwd(const MotCrossAttnDesc *desc /* host */, mot_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,8 @@ MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32, BF16 = 0, 1
 MAX_BPT = 64
-ABI_VERSION = 4
+ABI_VERSION = 5
+HEADS_AS_VIEWED, HEADS_PER_TOKEN = 0, 1
 
 
 def dtype_code(t: torch.dtype) -> int:
@@ -37,6 +38,7 @@ EXPORTS = (
     "mot_version", "mot_last_error", "mot_build_info", "mot_tokens_to_bytes", "mot_pull_bytes",
     "mot_create_batch", "mot_gather_rows", "mot_embed_mix_desc_size", "mot_embed_mix_workspace_bytes",
     "mot_embed_mix_fwd", "mot_embed_mix_bwd_workspace_bytes", "mot_embed_mix_bwd",
+    "mot_cross_attn_desc_size", "mot_cross_attn_workspace_bytes", "mot_cross_attn_fwd",
 )
 
 
@@ -69,6 +71,21 @@ class MotEmbedMixGrads(C.Structure):
     ]
 
 
+class MotCrossAttnDesc(C.Structure):
+    """Mirror of struct MotCrossAttnDesc (include/mot.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("dtype", C.c_int32), ("n_tokens", C.c_int64),
+        ("bpt", C.c_int32), ("n_heads", C.c_int32), ("head_layout", C.c_int32), ("dim", C.c_int32),
+        ("tokens", C.c_void_p), ("ids_a", C.c_void_p), ("ids_b", C.c_void_p),
+        ("tok_table", C.c_void_p), ("tok_rows", C.c_int64), ("byte_table", C.c_void_p), ("byte_rows", C.c_int64),
+        ("norm_tok", C.c_int32), ("norm_byte", C.c_int32),
+        ("q_w", C.c_void_p), ("kv_w", C.c_void_p), ("proj_w", C.c_void_p), ("lambda_factor", C.c_void_p),
+        ("cos_q", C.c_void_p), ("sin_q", C.c_void_p), ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
+        ("rot_q_len", C.c_int64), ("rot_k_len", C.c_int64), ("eps", C.c_float), ("reserved", C.c_int32),
+        ("out", C.c_void_p), ("status", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 def _load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise ImportError(
@@ -90,6 +107,11 @@ def _load() -> C.CDLL:
     lib.mot_embed_mix_bwd_workspace_bytes.restype = C.c_size_t
     lib.mot_embed_mix_bwd_workspace_bytes.argtypes = [C.POINTER(MotEmbedMixDesc)]
     lib.mot_embed_mix_bwd.argtypes = [C.POINTER(MotEmbedMixDesc), C.POINTER(MotEmbedMixGrads), vp]
+    lib.mot_cross_attn_desc_size.restype = C.c_size_t
+    lib.mot_cross_attn_workspace_bytes.restype = C.c_size_t
+    lib.mot_cross_attn_workspace_bytes.argtypes = [C.POINTER(MotCrossAttnDesc)]
+    lib.mot_cross_attn_fwd.argtypes = [C.POINTER(MotCrossAttnDesc), vp]
+    lib.mot_cross_attn_fwd.restype = C.c_int
     for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_gather_rows", "mot_embed_mix_fwd",
                  "mot_embed_mix_bwd"):
         getattr(lib, name).restype = C.c_int
@@ -97,6 +119,8 @@ def _load() -> C.CDLL:
         raise ImportError(f"libmot_hip.so ABI {lib.mot_version()} != binding ABI {ABI_VERSION}")
     if lib.mot_embed_mix_desc_size() != C.sizeof(MotEmbedMixDesc):
         raise ImportError("MotEmbedMixDesc layout mismatch between include/mot.h and _capi.py")
+    if lib.mot_cross_attn_desc_size() != C.sizeof(MotCrossAttnDesc):
+        raise ImportError("MotCrossAttnDesc layout mismatch between include/mot.h and _capi.py")
     return lib
 
 

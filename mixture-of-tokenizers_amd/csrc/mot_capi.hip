@@ -189,4 +189,43 @@ int mot_embed_mix_fwd(const MotEmbedMixDesc *desc, mot_stream_t stream) {
     return launch_embed_mix(*desc, (hipStream_t)stream);
 }
 
+size_t mot_cross_attn_desc_size(void) { return sizeof(MotCrossAttnDesc); }
+
+static int validate_cross_attn(const MotCrossAttnDesc *d) {
+    if (!d) return set_error(MOT_EINVAL, "cross_attn: null descriptor");
+    if (d->struct_size != sizeof(MotCrossAttnDesc))
+        return set_error(MOT_EINVAL, "cross_attn: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(MotCrossAttnDesc));
+    if (d->dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "cross_attn: only MOT_F32 is built");
+    if (d->n_tokens < 0) return set_error(MOT_ESHAPE, "cross_attn: negative shape");
+    int rc = check_bpt("cross_attn", d->bpt);
+    if (rc) return rc;
+    if (d->n_tokens * (int64_t)d->bpt * (d->n_heads > 0 ? d->n_heads : 1) > 0x7fffffffLL)
+        return set_error(MOT_EUNSUPPORTED, "cross_attn: T*bpt*heads exceeds 2^31");
+    if (d->n_heads < 1 || d->dim < 128 || d->n_heads * 128 > d->dim)
+        return set_error(MOT_ESHAPE, "cross_attn: n_heads %d x 128 does not fit dim %d (train_gpt.py:457-459: heads = dim // 128)", d->n_heads, d->dim);
+    if ((d->dim & 3) || d->dim > 1024) return set_error(MOT_EUNSUPPORTED, "cross_attn: dim %d must be a multiple of 4 and <= 1024", d->dim);
+    if (d->head_layout != MOT_HEADS_AS_VIEWED && d->head_layout != MOT_HEADS_PER_TOKEN)
+        return set_error(MOT_EINVAL, "cross_attn: bad head_layout %d", d->head_layout);
+    if (!d->tokens || !d->ids_a || !d->tok_table || !d->byte_table || !d->q_w || !d->kv_w || !d->proj_w || !d->lambda_factor || !d->out)
+        return set_error(MOT_EINVAL, "cross_attn: tokens/ids_a/tables/weights/lambda_factor/out must be non-null");
+    if (d->tok_rows <= 0 || d->byte_rows <= 0) return set_error(MOT_ESHAPE, "cross_attn: empty table");
+    if (!d->cos_q || !d->sin_q || !d->cos_k || !d->sin_k) return set_error(MOT_EINVAL, "cross_attn: rotary buffers missing");
+    if (d->rot_q_len < d->n_tokens || d->rot_k_len < d->n_tokens * (int64_t)d->bpt)   /* Rotary.forward's assert, line 200 */
+        return set_error(MOT_ESHAPE, "cross_attn: rotary buffers hold %lld / %lld positions, need %lld / %lld", (long long)d->rot_q_len,
+                         (long long)d->rot_k_len, (long long)d->n_tokens, (long long)(d->n_tokens * (int64_t)d->bpt));
+    return MOT_OK;
+}
+
+size_t mot_cross_attn_workspace_bytes(const MotCrossAttnDesc *desc) {
+    if (!desc || desc->struct_size != sizeof(MotCrossAttnDesc) || desc->n_heads < 1 || desc->bpt < 1 || desc->n_tokens < 0) return 0;
+    return cross_attn_workspace_bytes(*desc);
+}
+
+int mot_cross_attn_fwd(const MotCrossAttnDesc *desc, mot_stream_t stream) {
+    int rc = validate_cross_attn(desc);
+    if (rc) return rc;
+    if (desc->n_tokens == 0) return MOT_OK;
+    return launch_cross_attn(*desc, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -34,5 +34,7 @@ size_t embed_mix_linear_bf16_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix_linear_bf16(const MotEmbedMixDesc &d, hipStream_t stream);
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hipStream_t stream);
+size_t cross_attn_workspace_bytes(const MotCrossAttnDesc &d);
+int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream);
 
 }  // namespace mot

@@ -428,3 +428,62 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
             return MixResult(*r)
         return r
     return _embed_mix_fwd(tokens, tok_table, byte_table, scale_tok=scale_tok, scale_byte=scale_byte, **kw)
+
+
+@torch.compiler.disable
+def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor, *,
+               q_w: torch.Tensor, kv_w: torch.Tensor, proj_w: torch.Tensor, lambda_factor: torch.Tensor,
+               cos_q: torch.Tensor, sin_q: torch.Tensor, cos_k: torch.Tensor, sin_k: torch.Tensor,
+               bpt: int, n_heads: int, ids_b: torch.Tensor | None = None, norm_tok: bool = True, norm_byte: bool = True,
+               head_layout: str = "as_viewed", eps: float | None = None) -> torch.Tensor:
+    """The cross-attention byte mixin on top of the two embedding gathers (train_gpt.py:342-379, 446-464, 271-300):
+    tokens (1, T) -> (1, T, dim).  The reference asserts batch 1 (line 275).  fp32, forward only.
+    head_layout "as_viewed" reproduces the reference's reshape of k and v (lines 283-284); "per_token" is the
+    rearrange its comment names."""
+    if tokens.ndim == 1:
+        tokens = tokens[None]
+    assert tokens.shape[0] == 1, "Must use batch size = 1 for FlexAttention"      # train_gpt.py:275
+    params = (tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        raise RuntimeError("mixture-of-tokenizers_amd: the cross-attention mixin is forward-only so far; call it under "
+                           "torch.no_grad() or with frozen parameters")
+    dev = capi.require_device(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k)
+    T = tokens.shape[1]
+    tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
+    tok = tok if tok.is_contiguous() else tok.contiguous()
+    f32 = torch.float32
+    tt, bt = _contig(tok_table.detach(), f32, "tok_table"), _contig(byte_table.detach(), f32, "byte_table")
+    D = tt.shape[1]
+    if bt.shape[1] != D:
+        raise AssertionError("cross_attn: byte_dim == token_dim == model_dim (train_gpt.py:449)")
+    HD = n_heads * 128
+    qw, kvw, pw = _contig(q_w.detach(), f32, "q_w"), _contig(kv_w.detach(), f32, "kv_w"), _contig(proj_w.detach(), f32, "proj_w")
+    if qw.shape != (HD, D) or kvw.shape != (2, HD, D) or pw.shape != (D, HD):
+        raise AssertionError(f"cross_attn: weights {tuple(qw.shape)}, {tuple(kvw.shape)}, {tuple(pw.shape)} do not fit heads={n_heads}, dim={D}")
+    lam = _contig(lambda_factor.detach().reshape(1), f32, "lambda_factor")
+    ia = _contig(ids_a.reshape(-1), torch.int64, "ids_a")
+    ib = None if ids_b is None else _contig(ids_b.reshape(-1), torch.int64, "ids_b")
+    if ia.numel() != T * bpt or (ib is not None and ib.numel() != T * bpt):
+        raise AssertionError(f"cross_attn: byte ids must hold T*bpt = {T * bpt} entries")
+    rot = [_contig(t, f32, "rotary buffer") for t in (cos_q, sin_q, cos_k, sin_k)]
+    if any(r.ndim != 2 or r.shape[1] != 64 for r in rot):
+        raise AssertionError("cross_attn: rotary buffers must be (len, 64)")
+    out = torch.empty((1, T, D), dtype=f32, device=dev)
+    d = capi.MotCrossAttnDesc()
+    d.struct_size = C.sizeof(capi.MotCrossAttnDesc)
+    d.dtype, d.n_tokens, d.bpt, d.n_heads, d.dim = capi.F32, T, int(bpt), int(n_heads), D
+    d.head_layout = {"as_viewed": capi.HEADS_AS_VIEWED, "per_token": capi.HEADS_PER_TOKEN}[head_layout]
+    d.tokens, d.ids_a, d.ids_b = capi.ptr(tok), capi.ptr(ia), capi.ptr(ib)
+    d.tok_table, d.tok_rows, d.byte_table, d.byte_rows = capi.ptr(tt), tt.shape[0], capi.ptr(bt), bt.shape[0]
+    d.norm_tok, d.norm_byte = int(norm_tok), int(norm_byte)
+    d.q_w, d.kv_w, d.proj_w, d.lambda_factor = capi.ptr(qw), capi.ptr(kvw), capi.ptr(pw), capi.ptr(lam)
+    d.cos_q, d.sin_q, d.cos_k, d.sin_k = (capi.ptr(r) for r in rot)
+    d.rot_q_len, d.rot_k_len = rot[0].shape[0], rot[2].shape[0]
+    d.eps = float(eps or 0.0)
+    d.out, d.status = capi.ptr(out), capi.ptr(capi.status_word(dev))
+    ws = _workspace(dev, capi.lib.mot_cross_attn_workspace_bytes(C.byref(d)))
+    if ws is not None:
+        d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
+    capi.check(capi.lib.mot_cross_attn_fwd(C.byref(d), capi.stream_of(dev)))
+    capi.after_call(dev)
+    return out

@@ -238,13 +238,72 @@ class ByteMixinConcat(nn.Module):  # train_gpt.py:430-443
                            bytes_first=False, norm_out=True)
 
 
+class Rotary(nn.Module):  # train_gpt.py:188-207: the buffers, built with the same torch expressions
+    def __init__(self, dim: int, max_seq_len: int):
+        super().__init__()
+        angular_freq = (1 / 1024) ** torch.linspace(0, 1, steps=dim // 4, dtype=torch.float32)
+        angular_freq = torch.cat([angular_freq, angular_freq.new_zeros(dim // 4)])
+        t = torch.arange(max_seq_len, dtype=torch.float32)
+        theta = torch.einsum("i,j -> ij", t, angular_freq)
+        self.cos = nn.Buffer(theta.cos(), persistent=False)
+        self.sin = nn.Buffer(theta.sin(), persistent=False)
+
+
+class CrossAttention(nn.Module):
+    """train_gpt.py:243-300: every token attends to its own ``chars_per_token`` byte embeddings.  Same parameters
+    (q_w, kv_w, lambda_factor, c_proj.weight) and non-persistent Rotary buffers; forward takes the embedding
+    handle so the gathers, projections, per-head norm, RoPE and the softmax run in libmot_hip.so."""
+
+    def __init__(self, dim: int, num_heads: int, max_seq_len_q: int, max_seq_len_kv: int, head_dim=128,
+                 head_layout: Literal["as_viewed", "per_token"] = "as_viewed"):
+        super().__init__()
+        if head_dim != 128:
+            raise NotImplementedError("CrossAttention: head_dim 128 only (every instance the reference builds, train_gpt.py:459)")
+        self.num_heads, self.head_dim, self.head_layout = num_heads, head_dim, head_layout
+        hdim = num_heads * head_dim
+        bound = (3 ** 0.5) * 0.5 * (dim ** -0.5)
+        self.q_w = nn.Parameter(torch.empty(hdim, dim).uniform_(-bound, bound))
+        self.kv_w = nn.Parameter(torch.empty(2, hdim, dim).uniform_(-bound, bound))
+        self.lambda_factor = nn.Parameter(torch.tensor(0.5))
+        self.rotary_q = Rotary(head_dim, max_seq_len_q)
+        self.rotary_k = Rotary(head_dim, max_seq_len_kv)
+        self.c_proj = CastedLinear(hdim, dim)
+        self.attn_scale = 0.12   # kept for state parity; the reference's forward divides by sqrt(head_dim) instead (line 286)
+
+    def forward(self, xq, xkv=None) -> Tensor:
+        if not isinstance(xq, EmbedHandle):
+            raise NotImplementedError("CrossAttention: pass the EmbedHandle of a fused FlexibleEmbedding (materialised inputs are not built)")
+        h = xq
+        if h.scale_tok is not None or h.scale_byte is not None:
+            raise NotImplementedError("CrossAttention: learned embedding scalars are not part of this mixin")
+        return F_mot.cross_attn(h.tokens, h.ids_a, _f32(h.tok_weight, "token table"), _f32(h.byte_weight, "byte table"),
+                                ids_b=h.ids_b, q_w=self.q_w, kv_w=self.kv_w, proj_w=self.c_proj.weight, lambda_factor=self.lambda_factor,
+                                cos_q=self.rotary_q.cos, sin_q=self.rotary_q.sin, cos_k=self.rotary_k.cos, sin_k=self.rotary_k.sin,
+                                bpt=h.bpt, n_heads=self.num_heads, norm_tok=h.norm_tok, norm_byte=h.norm_byte, head_layout=self.head_layout)
+
+
+class ByteMixinCrossAttn(nn.Module):  # train_gpt.py:446-464
+    def __init__(self, dims: ModelDims, max_seq_len: int, byte_params: ByteHyperparameters):
+        super().__init__()
+        assert dims.byte_dim == dims.token_dim == dims.model_dim
+        self.byte_params = byte_params
+        if byte_params.use_byte_self_attn:
+            raise NotImplementedError("use_byte_self_attn (ByteSelfAttn, train_gpt.py:382-418) is outside the front-end path")
+        self.attention = nn.Identity()
+        self.mixin = CrossAttention(dim=dims.model_dim, num_heads=dims.model_dim // 128,
+                                    max_seq_len_kv=max_seq_len * byte_params.bytes_per_token, max_seq_len_q=max_seq_len, head_dim=128)
+
+    def forward(self, token_embs, byte_embs=None) -> Tensor:
+        return self.mixin(xq=token_embs, xkv=byte_embs)
+
+
 class ByteMixin(nn.Module):  # train_gpt.py:467-480
     def __init__(self, dims: ModelDims, max_seq_len: int, byte_params: ByteHyperparameters):
         super().__init__()
         if byte_params.byte_mixin_method == "noop":
             self.mixin = ByteMixinNoop(dims, max_seq_len, byte_params)
         elif byte_params.byte_mixin_method == "cross_attn":
-            raise NotImplementedError("byte_mixin_method='cross_attn' (train_gpt.py:446-464) is a later scope row")
+            self.mixin = ByteMixinCrossAttn(dims, max_seq_len, byte_params)
         elif byte_params.byte_mixin_method == "concat":
             self.mixin = ByteMixinConcat(dims, max_seq_len, byte_params)
         else:

@@ -74,7 +74,7 @@ def load_train_gpt_defs() -> dict:
     from torch import Tensor, nn
     ns = dict(torch=torch, nn=nn, F=F, Tensor=Tensor, einops=einops, dataclass=dataclass, Literal=Literal)
     names = {"ByteHyperparameters", "ModelDims", "norm", "CastedLinear", "FlexibleEmbedding",
-             "ByteMixinNoop", "ByteMixinConcat", "ByteMixin"}
+             "ByteMixinNoop", "ByteMixinConcat", "ByteMixin", "Rotary", "CrossAttention", "ByteMixinCrossAttn"}
     # the dataclasses keep their decorators
     return _exec_nodes(REF / "scaled-pre-train" / "train_gpt.py", names, ns, strip_decorators=False)
 
@@ -500,7 +500,48 @@ def gen_bf16(dc, tg, r71):
     print("bf16:", len(out), "arrays")
 
 
+# ------------------------------------------------------------------ G6: cross-attention mixin (train_gpt.py:243-300, 446-464)
+def gen_cross_attn(dc, tg):
+    out = {}
+    for (name, Vt, D, bpt, T, seed) in gi.CROSS_CASES:
+        tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+        toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+        padded = dc.tokens_to_bytes(torch.from_numpy(toks), ttb_embedding(tab))
+        pulled = dc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+        Et, Eb = gi.normal_table(seed + 1, Vt, D), gi.normal_table(seed + 2, gi.BYTE_VOCAB, D)
+        q_w, kv_w, p_w = gi.cross_weights(seed + 3, D)
+        out[f"{name}/tokens"], out[f"{name}/padded"], out[f"{name}/pulled"] = toks, t2n(padded), t2n(pulled)
+        for mode, bp_kw in (("pulled", dict(pull_in=True)), ("padded_and_pulled", dict(pull_in=True, add_padded_and_pulled=True))):
+            for dt_name, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+                bp = tg["ByteHyperparameters"](bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="cross_attn", **bp_kw)
+                dims = tg["ModelDims"](model_dim=D, byte_dim=D, token_dim=D)
+                emb = tg["FlexibleEmbedding"](dims, Vt, bp)
+                mix = tg["ByteMixin"](dims, T, bp)
+                assert sorted(dict(mix.state_dict())) == ["mixin.mixin.c_proj.weight", "mixin.mixin.kv_w", "mixin.mixin.lambda_factor",
+                                                          "mixin.mixin.q_w"]
+                if dt_name == "f32" and mode == "pulled":   # the module's own Rotary buffers (non-persistent)
+                    out[f"{name}/cos_q"], out[f"{name}/sin_q"] = t2n(mix.mixin.mixin.rotary_q.cos), t2n(mix.mixin.mixin.rotary_q.sin)
+                    out[f"{name}/cos_k"], out[f"{name}/sin_k"] = t2n(mix.mixin.mixin.rotary_k.cos), t2n(mix.mixin.mixin.rotary_k.sin)
+                emb, mix = emb.to(tdt), mix.to(tdt)
+                emb.embed_tokens.weight.data = torch.from_numpy(Et).to(tdt)
+                emb.embed_bytes.weight.data = torch.from_numpy(Eb).to(tdt)
+                ca = mix.mixin.mixin
+                ca.q_w.data, ca.kv_w.data = torch.from_numpy(q_w).to(tdt), torch.from_numpy(kv_w).to(tdt)
+                ca.c_proj.weight.data = torch.from_numpy(p_w).to(tdt)
+                ca.lambda_factor.data = torch.tensor(0.7, dtype=tdt)
+                with torch.no_grad():
+                    xt, xb = emb(tokens=torch.from_numpy(toks), byte_tensor=padded, byte_tensor_pulled=pulled)
+                    x = mix(xt, xb)
+                assert x.shape == (1, T, D)
+                out[f"{name}/{mode}/{dt_name}/x"] = t2n(x)
+    np.savez_compressed(OUT / "cross_attn.npz", **out)
+    print("cross_attn:", len(out), "arrays")
+
+
 def main():
+    if sys.argv[1:] == ["cross_attn"]:          # regenerate one fixture without touching the others
+        gen_cross_attn(load_data_creation(), load_train_gpt_defs())
+        return
     dc = load_data_creation()
     gen_ttb_fixture()
     gen_index(dc)
@@ -512,6 +553,7 @@ def main():
     gen_mathblations(*mm)
     gen_grads(dc, load_train_gpt_defs(), load_run71_defs(), mm[0])
     gen_bf16(dc, load_train_gpt_defs(), load_run71_defs())
+    gen_cross_attn(dc, load_train_gpt_defs())
     meta = dict(torch=torch.__version__, numpy=np.__version__, python=sys.version.split()[0],
                 threads=torch.get_num_threads(), reference="snimu/mixture-of-tokenizers @ 2025-08-24",
                 generator="oracle/gen_golden.py")

@@ -285,6 +285,7 @@ static double bf16_rne(double x) {
 #define REAL_EPS 1.1920928955078125e-07 /* torch.finfo(float32).eps: F.rms_norm eps=None */
 #define REAL_RSQRT(v) ((REAL)(1.0f / sqrtf((float)(v))))
 #include "mot_oracle_float.inc"
+#include "mot_oracle_attn.inc"
 #undef REAL
 #undef ACC
 #undef SUFFIX
@@ -297,3 +298,4 @@ static double bf16_rne(double x) {
 #define REAL_EPS 2.220446049250313e-16 /* torch.finfo(float64).eps */
 #define REAL_RSQRT(v) (1.0 / sqrt((double)(v)))
 #include "mot_oracle_float.inc"
+#include "mot_oracle_attn.inc"

@@ -251,3 +251,34 @@ def embed_mix_bwd(tokens, ids_a, ids_b, tok_table, byte_table, grad_out, *, mode
               _p(d_tok, C.c_double), _p(d_byte, C.c_double), _p(d_w, C.c_double), _p(d_b, C.c_double),
               _p(d_s, C.c_double)), "embed_mix_bwd")
     return dict(tok_table=d_tok, byte_table=None if m == MODE_NOOP else d_byte, weight=d_w, bias=d_b, scales=d_s)
+
+
+def cross_attn(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor,
+               cos_q, sin_q, cos_k, sin_k, *, bpt, n_heads, head_dim=128, norm_tok=True, norm_byte=True,
+               head_layout=0, dtype=np.float32):
+    """ByteMixinCrossAttn on FlexibleEmbedding's outputs, batch 1 (mot_oracle_attn.inc; train_gpt.py:271-300,
+    446-464).  tokens (T,), ids (T*bpt,), tables (rows, D), q_w (H*hd, D), kv_w (2, H*hd, D), proj_w (D, H*hd);
+    cos/sin: the Rotary buffers, float32 (len, hd/2).  head_layout 0 = the reference's .view()."""
+    real = C.c_float if dtype == np.float32 else C.c_double
+    fn = lib().oracle_cross_attn_f32 if dtype == np.float32 else lib().oracle_cross_attn_f64
+    tok = _c(tokens, np.int32).reshape(-1)
+    T = tok.size
+    tt, bt = _c(tok_table, dtype), _c(byte_table, dtype)
+    D = tt.shape[1]
+    assert bt.shape[1] == D
+    ia = _c(ids_a, np.int64).reshape(-1)
+    ib = None if ids_b is None else _c(ids_b, np.int64).reshape(-1)
+    assert ia.size == T * bpt
+    qw, kvw, pw = _c(q_w, dtype), _c(kv_w, dtype), _c(proj_w, dtype)
+    HD = n_heads * head_dim
+    assert qw.shape == (HD, D) and kvw.shape == (2, HD, D) and pw.shape == (D, HD)
+    cq, sq, ck, sk = (_c(a, np.float32) for a in (cos_q, sin_q, cos_k, sin_k))
+    assert cq.shape[0] >= T and ck.shape[0] >= T * bpt and cq.shape[1] == head_dim // 2
+    out = np.empty((T, D), dtype=dtype)
+    _check(fn(_p(tok, C.c_int32), C.c_int64(T), _p(ia, C.c_int64), _p(ib, C.c_int64), C.c_int(bpt),
+              _p(tt, real), C.c_int64(tt.shape[0]), _p(bt, real), C.c_int64(bt.shape[0]), C.c_int(D),
+              C.c_int(int(norm_tok)), C.c_int(int(norm_byte)),
+              _p(qw, real), _p(kvw, real), _p(pw, real), C.c_int(n_heads), C.c_int(head_dim), C.c_double(float(lambda_factor)),
+              _p(cq, C.c_float), _p(sq, C.c_float), _p(ck, C.c_float), _p(sk, C.c_float),
+              C.c_int(head_layout), _p(out, real)), "cross_attn")
+    return out

@@ -174,3 +174,21 @@ RAW_INDEX_CASES = [
     ("raw_b16", 16, 3, 300, 202),
     ("raw_b5", 5, 2, 64, 203),
 ]
+
+
+def cross_weights(seed, D):
+    """q_w (D, D), kv_w (2, D, D) ~ U(+-sqrt(3)*0.5/sqrt(D)) as CrossAttention.__init__ draws them
+    (train_gpt.py:257-263), c_proj weight as CastedLinear; heads = D // 128."""
+    rs = np.random.RandomState(seed)
+    bound = (3 ** 0.5) * 0.5 * (D ** -0.5)
+    q_w = rs.uniform(-bound, bound, (D, D)).astype(np.float32)
+    kv_w = rs.uniform(-bound, bound, (2, D, D)).astype(np.float32)
+    return q_w, kv_w, casted_linear_weight(seed + 1, D, D)
+
+
+CROSS_CASES = [
+    # name, Vt, D (= token = byte = model dim; heads = D/128), bpt, T, seed
+    ("h1", 97, 128, 4, 12, 701),        # one head: the .view() of train_gpt.py:283-284 is the identity permutation
+    ("h2", 97, 256, 8, 24, 702),
+    ("c2dims", 512, 768, 16, 40, 703),  # 6 heads, bpt 16
+]

@@ -1,0 +1,104 @@
+"""-m gpu: the cross-attention byte mixin (train_gpt.py:243-300, 446-464) through the module interface
+(FlexibleEmbedding -> ByteMixin(byte_mixin_method="cross_attn")) and through functional.cross_attn.
+
+Tolerance (fp32 path with two D x D contractions, a per-head norm and a softmax in between): measured against the
+float64 evaluation, relative to the largest output entry --
+    max|hip - ref64| <= 2 * max(max|ref32 - ref64|, 1e-6 * max|ref64|)
+where ref32 / ref64 are the reference's own fp32 and float64 outputs (tests/golden/cross_attn.npz); i.e. the kernel
+may be at most twice as far from exact as the reference's fp32 CPU run (same criterion as CONCAT_LINEAR).  Against
+the float64 oracle at sizes without a golden the bar is 5e-6 of max|ref64|."""
+import numpy as np
+import pytest
+import torch
+
+import golden_inputs as gi
+from oracle import oracle as orc
+from util_gpu import DEV, dev, f32, host
+
+pytestmark = pytest.mark.gpu
+G = gi.GOLDEN_DIR
+
+
+@pytest.fixture(scope="module")
+def mot():
+    import mixture_of_tokenizers_amd as m
+    return m
+
+
+def build(M, Vt, D, bpt, T, seed, mode):
+    bp = M.ByteHyperparameters(bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="cross_attn", pull_in=True,
+                               add_padded_and_pulled=mode == "padded_and_pulled")
+    dims = M.ModelDims(model_dim=D, byte_dim=D, token_dim=D)
+    embed, mixin = M.FlexibleEmbedding(dims, Vt, bp).to(DEV), M.ByteMixin(dims, T, bp).to(DEV)
+    q_w, kv_w, p_w = gi.cross_weights(seed + 3, D)
+    ca = mixin.mixin.mixin
+    with torch.no_grad():
+        embed.embed_tokens.weight.copy_(dev(f32(gi.normal_table(seed + 1, Vt, D))))
+        embed.embed_bytes.weight.copy_(dev(f32(gi.normal_table(seed + 2, gi.BYTE_VOCAB, D))))
+        ca.q_w.copy_(dev(q_w)); ca.kv_w.copy_(dev(kv_w)); ca.c_proj.weight.copy_(dev(p_w)); ca.lambda_factor.fill_(0.7)
+    return embed, mixin
+
+
+@pytest.mark.parametrize("mode", ["pulled", "padded_and_pulled"])
+@pytest.mark.parametrize("case", gi.CROSS_CASES, ids=lambda c: c[0])
+def test_cross_attn_modules_vs_reference(mot, case, mode):
+    from mixture_of_tokenizers_amd import modules as M
+    name, Vt, D, bpt, T, seed = case
+    z = np.load(G / "cross_attn.npz")
+    embed, mixin = build(M, Vt, D, bpt, T, seed, mode)
+    assert sorted(mixin.state_dict()) == ["mixin.mixin.c_proj.weight", "mixin.mixin.kv_w", "mixin.mixin.lambda_factor", "mixin.mixin.q_w"]
+    with torch.no_grad():
+        x = mixin(*embed(tokens=dev(z[f"{name}/tokens"]), byte_tensor=dev(z[f"{name}/padded"]), byte_tensor_pulled=dev(z[f"{name}/pulled"])))
+    assert x.shape == (1, T, D) and x.dtype == torch.float32
+    r32, r64 = z[f"{name}/{mode}/f32/x"], z[f"{name}/{mode}/f64/x"]
+    scale = np.abs(r64).max()
+    bar = 2 * max(np.abs(r32.astype(np.float64) - r64).max(), 1e-6 * scale)
+    assert np.abs(host(x).astype(np.float64) - r64).max() <= bar
+
+
+@pytest.mark.parametrize("D,bpt,Vt,T,layout,dual,seed", [
+    (768, 16, 4096, 300, "as_viewed", False, 9901),      # C2 dims: 6 heads
+    (768, 16, 4096, 300, "per_token", False, 9902),
+    (1024, 16, 2048, 130, "as_viewed", False, 9903),     # production dims: 8 heads
+    (256, 5, 512, 77, "as_viewed", True, 9904),          # two id tensors: keys depend on the id pair
+    (384, 7, 300, 33, "per_token", True, 9905),
+])
+def test_cross_attn_vs_oracle(mot, D, bpt, Vt, T, layout, dual, seed):
+    from mixture_of_tokenizers_amd.modules import Rotary
+    H = D // 128
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=min(4.4, bpt / 2))
+    toks = gi.fineweb_like_tokens(seed, 1, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, D))
+    q_w, kv_w, p_w = gi.cross_weights(seed + 4, D)
+    padded = orc.tokens_to_bytes(toks, tab.astype(np.float32))
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    rq, rk = Rotary(128, T + 3), Rotary(128, T * bpt + 5)       # longer buffers than needed, as with max_seq_len
+    rot = [rq.cos, rq.sin, rk.cos, rk.sin]
+    d64 = lambda a: np.asarray(a, dtype=np.float64)
+    ref = orc.cross_attn(toks[0], pulled[0], padded[0] if dual else None, d64(Et), d64(Eb), d64(q_w), d64(kv_w), d64(p_w), 0.35,
+                         *[r.numpy() for r in rot], bpt=bpt, n_heads=H, dtype=np.float64, head_layout=0 if layout == "as_viewed" else 1)
+    x = mot.functional.cross_attn(dev(toks), dev(pulled), dev(Et), dev(Eb), ids_b=dev(padded) if dual else None,
+                                  q_w=dev(f32(q_w)), kv_w=dev(f32(kv_w)), proj_w=dev(f32(p_w)), lambda_factor=torch.tensor(0.35, device=DEV),
+                                  cos_q=rot[0].to(DEV), sin_q=rot[1].to(DEV), cos_k=rot[2].to(DEV), sin_k=rot[3].to(DEV),
+                                  bpt=bpt, n_heads=H, head_layout=layout)
+    mot.check_status()
+    assert np.abs(host(x)[0].astype(np.float64) - ref).max() <= 5e-6 * np.abs(ref).max()
+
+
+def test_cross_attn_errors(mot):
+    from mixture_of_tokenizers_amd import modules as M
+    Vt, D, bpt, T = 97, 256, 8, 24
+    embed, mixin = build(M, Vt, D, bpt, T, 702, "pulled")
+    toks = torch.zeros((1, T), dtype=torch.int32, device=DEV)
+    ids = torch.zeros((1, T * bpt), dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError, match="forward-only"):        # parameters require grad
+        mixin(*embed(toks, ids, ids))
+    with torch.no_grad():
+        with pytest.raises(AssertionError, match="batch size = 1"):    # train_gpt.py:275
+            mixin(*embed(toks.repeat(2, 1), ids.repeat(2, 1), ids.repeat(2, 1)))
+        with pytest.raises(AssertionError):                            # Rotary.forward's length assert, line 200
+            mixin(*embed(toks.repeat(1, 2), ids.repeat(1, 2), ids.repeat(1, 2)))
+        bad = ids.clone(); bad[0, 5] = 999
+        mixin(*embed(toks, bad, bad))
+        with pytest.raises(IndexError):
+            mot.check_status()

@@ -254,3 +254,41 @@ def test_backward_oracle_vs_reference_autograd(case):
     if f"{base}/f64/d_scalars" in z:      # [-2] bytes, [-1] tokens (runs/71041_*.py:311-312)
         ref = z[f"{base}/f64/d_scalars"]
         assert abs(f64["scales"][0] - ref[1]) < 1e-9 * abs(ref).max() and abs(f64["scales"][1] - ref[0]) < 1e-9 * abs(ref).max()
+
+
+# ---------------------------------------------------------------------------------------------
+# cross-attention mixin (train_gpt.py:243-300, 446-464): oracle vs what the reference produced
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", gi.CROSS_CASES, ids=lambda c: c[0])
+def test_cross_attn_oracle_vs_reference(case):
+    name, Vt, D, bpt, T, seed = case
+    z = np.load(G / "cross_attn.npz")
+    Et, Eb = gi.normal_table(seed + 1, Vt, D), gi.normal_table(seed + 2, gi.BYTE_VOCAB, D)
+    q_w, kv_w, p_w = gi.cross_weights(seed + 3, D)
+    rot = [z[f"{name}/{k}"] for k in ("cos_q", "sin_q", "cos_k", "sin_k")]
+    for mode in ("pulled", "padded_and_pulled"):
+        ids_b = z[f"{name}/padded"] if mode == "padded_and_pulled" else None
+        for dn, dt, tol in (("f32", np.float32, 2e-6), ("f64", np.float64, 1e-12)):
+            x = orc.cross_attn(z[f"{name}/tokens"], z[f"{name}/pulled"], ids_b, Et.astype(dt), Eb.astype(dt), q_w.astype(dt),
+                               kv_w.astype(dt), p_w.astype(dt), 0.7, *rot, bpt=bpt, n_heads=D // 128, dtype=dt)
+            ref = z[f"{name}/{mode}/{dn}/x"][0]
+            assert np.abs(x - ref).max() <= tol * np.abs(ref).max(), (mode, dn)
+    # the reference reshapes k, v into (H, T, bpt, hd) instead of transposing (lines 283-284): with more than one head
+    # the per-token reading of its comment is a different function, with one head it is the same
+    x1 = orc.cross_attn(z[f"{name}/tokens"], z[f"{name}/pulled"], None, Et.astype(np.float64), Eb.astype(np.float64), q_w.astype(np.float64),
+                        kv_w.astype(np.float64), p_w.astype(np.float64), 0.7, *rot, bpt=bpt, n_heads=D // 128, dtype=np.float64,
+                        head_layout=1)
+    diff = np.abs(x1 - z[f"{name}/pulled/f64/x"][0]).max()
+    assert diff < 1e-12 if D == 128 else diff > 0.1
+
+
+def test_rotary_buffers_match_the_reference_bit_for_bit():
+    """modules.Rotary builds cos/sin with the reference's torch expressions (train_gpt.py:190-197)."""
+    from mixture_of_tokenizers_amd.modules import Rotary
+    z = np.load(G / "cross_attn.npz")
+    for name, Vt, D, bpt, T, seed in gi.CROSS_CASES:
+        rq, rk = Rotary(128, T), Rotary(128, T * bpt)
+        np.testing.assert_array_equal(rq.cos.numpy(), z[f"{name}/cos_q"])
+        np.testing.assert_array_equal(rq.sin.numpy(), z[f"{name}/sin_q"])
+        np.testing.assert_array_equal(rk.cos.numpy(), z[f"{name}/cos_k"])
+        np.testing.assert_array_equal(rk.sin.numpy(), z[f"{name}/sin_k"])
