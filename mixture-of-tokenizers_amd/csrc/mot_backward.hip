@@ -55,11 +55,19 @@ struct BwdArgs {
     // layout of one gradient row of D elements: token part [tok_lo, tok_lo+Dt), byte part [byte_lo, byte_lo+bpt*Db).
     // SUM: both parts span the whole row (x = a + concat b); CONCAT_LINEAR: they are the two halves of du = dy.W
     int Dt, tok_lo, byte_lo, nbk;
-    int privatize;  // byte-table gradient accumulated in LDS
+    // byte-table gradient privatised in LDS as 64-bit fixed point: rows [0, priv_lo) and [priv_hi0, byte_rows) have a slot
+    // (everything when the table fits; otherwise the raw byte values and the trailing specials such as pad / eot)
+    int priv_lo, priv_hi0, priv_rows;
     const int32_t *pos_sorted;  // token positions ordered by token id
     int in_bf16;  // tables and grad_out are bf16 (gradients are accumulated and returned in fp32 either way)
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
 };
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 
 // element i of a float or bf16 array (uniform choice per launch)
 __device__ __forceinline__ float ld_in(const float *base, int64_t i, int bf16) {
@@ -68,14 +76,34 @@ __device__ __forceinline__ float ld_in(const float *base, int64_t i, int bf16) {
 
 template <int MODE, int NE>
 __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArgs A) {
-    extern __shared__ float lds_f[];
+    extern __shared__ unsigned long long lds_q[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nbyte = A.privatize ? (int)A.byte_rows * A.Db : 0;
-    float *dbyte_l = lds_f;                           // [byte_rows*Db]
-    float *seg = lds_f + nbyte + wave * kMaxBpt;      // per-wave per-slot dot products
-    float *segr = lds_f + nbyte + (kBwdWaves + wave) * kMaxBpt;  // per-wave per-slot rms factor (two-id-tensor norm)
-    for (int i = tid; i < nbyte; i += kBwdThreads) dbyte_l[i] = 0.f;
+    const int nbyte = A.priv_rows * A.Db;
+    unsigned long long *dbyte_q = lds_q;              // [priv_rows*Db] fixed-point sums (two's complement)
+    float *lds_f = (float *)(lds_q + nbyte);
+    float *seg = lds_f + wave * kMaxBpt;              // per-wave per-slot dot products
+    float *segr = lds_f + (kBwdWaves + wave) * kMaxBpt;  // per-wave per-slot rms factor (two-id-tensor norm)
+    uint32_t *fx_bits = (uint32_t *)(lds_f + 2 * kBwdWaves * kMaxBpt);  // max |v| over the waves' first tokens (float bits)
+    for (int i = tid; i < nbyte; i += kBwdThreads) dbyte_q[i] = 0ull;
+    if (tid == 0) *fx_bits = 0u;
     __syncthreads();
+    // LDS float atomics run one lane at a time on gfx950 (ds_add_f32: ~190 cycles per wave-instruction, ds_add_u64: ~20,
+    // tools/ubench/lds_atomic.hip), so the privatised sums are 64-bit fixed point: v * 2^fx_k, fx_k chosen per workgroup so
+    // that the largest |v| of the waves' first tokens lands at 2^28.  Terms outside [2^12, 2^40) after scaling (too coarse /
+    // too close to the 2^62 budget of <= 2^22 adds) and rows without a slot take the exact global float atomic instead,
+    // so the result never depends on the choice of scale -- only the speed does.
+    int fx_k = 0;
+    bool fx_pending = MODE != MOT_MIX_NOOP;
+    auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
+    auto add_byte = [&](int id, int wi, float v) {
+        const int sl = byte_slot(id);
+        const float x = rintf(ldexpf(v, fx_k)), ax = fabsf(x);
+        if (sl >= 0 && ax < 0x1p40f && (ax >= 0x1p12f || v == 0.f)) {
+            if (v != 0.f) atomicAdd(dbyte_q + sl * A.Db + wi, (unsigned long long)(long long)x);
+        } else {
+            atomicAdd(A.d_byte + id * A.Db + wi, v);   // exact path (also carries inf / nan through)
+        }
+    };
 
     const int D = A.D;
     const float inv_db = MODE != MOT_MIX_NOOP ? 1.0f / (float)A.Db : 0.f;
@@ -171,7 +199,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
         if (pair_norm) {
             // norm(emb(padded) + emb(pulled)) (train_gpt.py:378): the rms factor belongs to the (token, slot) pair,
             // not to a table row -- reduce sum(b^2) per slot through the wave's LDS accumulators
-            if (lane < A.bpt) segr[lane] = 0.f;
+            segr[lane] = 0.f;   // all 64 lanes (kMaxBpt entries): a `lane < bpt` guard lets the compiler reorder the adds around it
             __threadfence_block();
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
@@ -179,7 +207,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
                 if (eb >= 0) atomicAdd(&segr[slot_of(eb)], bn[j] * bn[j]);
             }
             __threadfence_block();
-            if (lane < A.bpt) segr[lane] = rms_scale(segr[lane], A.Db, A.eps);
+            segr[lane] = rms_scale(segr[lane], A.Db, A.eps);
             __threadfence_block();
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
@@ -238,7 +266,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
             for (int j = 0; j < NE; ++j) dot += dy[j] * bn[j];
             ds_b += dot;
             if (A.norm_byte) {  // per-slot mean(db * b_n): slots are ragged lane groups -> LDS accumulators
-                if (lane < A.bpt) seg[lane] = 0.f;
+                seg[lane] = 0.f;
                 __threadfence_block();
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
@@ -247,24 +275,36 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
                 }
                 __threadfence_block();
             }
+            float vmax = 0.f;
 #pragma unroll
-            for (int j = 0; j < NE; ++j) {
+            for (int j = 0; j < NE; ++j) {   // dy[j] <- gradient w.r.t. the (un-normalised) byte-table element
                 const int eb = byte_off(lane + 64 * j);
                 if (eb < 0) continue;
-                const int sl = slot_of(eb), wi = eb - sl * A.Db;
+                const int sl = slot_of(eb);
                 const float db = dy[j] * s_byte;
                 float v = db;
                 if (A.norm_byte) v = (pair_norm ? segr[sl] : A.byte_rnorm[id1[j]]) * (db - bn[j] * (seg[sl] / (float)A.Db));
-                // two explicit address spaces (ds_add_f32 / global_atomic_add_f32): a pointer that may be
-                // either would become a flat atomic, which faults on the LDS aperture
-                const int i1 = id1[j] * A.Db + wi;
-                if (A.abl & 1) continue;
-                if (A.privatize) atomicAdd(dbyte_l + i1, v); else atomicAdd(A.d_byte + i1, v);
+                dy[j] = v;
+                vmax = fmaxf(vmax, fabsf(v));
+            }
+            if (fx_pending) {   // once per wave: agree on the workgroup's fixed-point scale
+                vmax = wave_max(vmax);
+                if (lane == 0 && vmax > 0.f && vmax < INFINITY) atomicMax(fx_bits, __float_as_uint(vmax));
+                __syncthreads();
+                const float m = __uint_as_float(*fx_bits);
+                fx_k = m > 0.f ? 28 - ilogbf(m) : 0;
+                fx_pending = false;
+            }
+#pragma unroll
+            for (int j = 0; j < NE; ++j) {
+                const int eb = byte_off(lane + 64 * j);
+                if (eb < 0 || (A.abl & 1)) continue;
+                const int sl = slot_of(eb), wi = eb - sl * A.Db;
+                add_byte(id1[j], wi, dy[j]);
                 if (A.ids_b) {
                     int64_t ib = A.ids_b[n * A.bpt + sl];
                     if ((uint64_t)ib >= (uint64_t)A.byte_rows) ib = 0;
-                    const int i2 = (int)ib * A.Db + wi;
-                    if (A.privatize) atomicAdd(dbyte_l + i2, v); else atomicAdd(A.d_byte + i2, v);
+                    add_byte((int)ib, wi, dy[j]);
                 }
             }
             if (A.norm_byte) __threadfence_block();  // seg is rewritten by the next token
@@ -275,11 +315,255 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
     flush();
     if (A.d_scale_tok) { ds_t = wave_sum(ds_t); if (lane == 0) atomicAdd(A.d_scale_tok, ds_t); }
     if (MODE != MOT_MIX_NOOP && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
-    if (A.privatize) {
+    if (MODE != MOT_MIX_NOOP) {
+        if (fx_pending) {   // a wave without work still meets the others at the scale barrier
+            __syncthreads();
+            const float m = __uint_as_float(*fx_bits);
+            fx_k = m > 0.f ? 28 - ilogbf(m) : 0;
+        }
         __syncthreads();
         for (int i = tid; i < nbyte; i += kBwdThreads) {
-            const float v = dbyte_l[i];
-            if (v != 0.f) atomicAdd(A.d_byte + i, v);
+            const long long q = (long long)dbyte_q[i];
+            if (q == 0) continue;
+            const int sl = i / A.Db, wi = i - sl * A.Db;
+            const int row = sl < A.priv_lo ? sl : sl - A.priv_lo + A.priv_hi0;
+            atomicAdd(A.d_byte + row * A.Db + wi, (float)ldexp((double)q, -fx_k));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Lean variant for the layouts where a row is "full": SUM / NOOP with D == 64 * NE (the headline shapes: 768, 1024,
+// 2048, 256 ...).  Same algorithm as embed_mix_bwd_kernel, minus everything the general layout needs per element
+// (range guards, the split token/byte row layout of CONCAT_LINEAR, the two-id-tensor norm): the slot and
+// within-slot index of a lane's elements are computed once, a token's byte ids are loaded once by lanes < bpt and
+// handed out with ds_bpermute, and the per-slot sums of the byte-norm backward use the same fixed-point LDS
+// accumulation as the table.  ~4x fewer instructions per token than the general kernel.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long to_fixed(float v, int k) {
+    // round(v * 2^k) as two's complement in 64 bits, |v * 2^k| < 2^51: add 1.5 * 2^52 and read the mantissa
+    const double d = ldexp((double)v, k) + 6755399441055744.0;
+    return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
+}
+
+template <int MODE, int NE>
+__global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const BwdArgs A) {
+    constexpr int D = 64 * NE;
+    extern __shared__ unsigned long long lds_q[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nbyte = A.priv_rows * A.Db;
+    unsigned long long *dbyte_q = lds_q;
+    unsigned long long *seg_q = lds_q + nbyte + wave * kMaxBpt;                      // per-wave per-slot sums (byte-norm backward)
+    uint32_t *fx_bits = (uint32_t *)(lds_q + nbyte + kBwdWaves * kMaxBpt);
+    for (int i = tid; i < nbyte; i += kBwdThreads) dbyte_q[i] = 0ull;
+    if (tid == 0) *fx_bits = 0u;
+    __syncthreads();
+    const bool dual = MODE == MOT_MIX_SUM && A.ids_b != nullptr;
+    const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
+    const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
+    float ds_t = 0.f, ds_b = 0.f;
+    int slw[NE];   // element lane + 64 j of a row: byte slot in bits 16.., index within the slot in bits 0..15
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e = lane + 64 * j, sl = MODE == MOT_MIX_SUM ? e / A.Db : 0;
+        slw[j] = (sl << 16) | (e - sl * A.Db);
+    }
+    int fx_k = 0;
+    float fx_hi = 0.f;      // |v| at or above this (or non-finite) takes the exact global atomic
+    bool fx_pending = MODE != MOT_MIX_NOOP;
+    auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
+
+    float acc[NE];
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+        float *drow = A.d_tok + (int64_t)cur * D + lane;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) atomicAdd(drow + 64 * j, acc[j]);
+    };
+    auto load_tok = [&](int64_t n) {
+        int t = A.tokens[n];
+        if ((uint64_t)(uint32_t)t >= (uint64_t)A.tok_rows) {
+            if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
+            t = 0;
+        }
+        return t;
+    };
+    auto load_id = [&](const int64_t *ids, int64_t n) {   // lanes < bpt: the token's byte ids, clamped once
+        int64_t v = 0;
+        if (lane < A.bpt) {
+            v = ids[n * A.bpt + lane];
+            if ((uint64_t)v >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); v = 0; }
+        }
+        return (int)v;
+    };
+    const int64_t nwin = (A.n_tokens + kWindow - 1) / kWindow;
+    for (int64_t w = (int64_t)blockIdx.x * kBwdWaves + wave; w < nwin; w += (int64_t)gridDim.x * kBwdWaves) {
+        const int64_t s_end = min(A.n_tokens, (w + 1) * kWindow);
+        int64_t n_nx = A.pos_sorted[w * kWindow];
+        int tok_nx = load_tok(n_nx);
+        int ida_nx = 0, idb_nx = 0;
+        if (MODE == MOT_MIX_SUM) { ida_nx = load_id(A.ids_a, n_nx); if (dual) idb_nx = load_id(A.ids_b, n_nx); }
+        for (int64_t si = w * kWindow; si < s_end; ++si) {
+            const int64_t n = n_nx;
+            const int tok = tok_nx, ida = ida_nx, idb = idb_nx;
+            n_nx = A.pos_sorted[min(si + 1, s_end - 1)];
+            if (tok != cur) {
+                flush();
+                cur = tok;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) acc[j] = 0.f;
+            }
+            float an[NE], bn[NE], dy[NE];
+            int idj[NE];
+            const int64_t trow = (int64_t)tok * D + lane, grow = n * D + lane;
+            if (A.in_bf16) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    an[j] = (float)((const __bf16 *)A.tok_table)[trow + 64 * j];
+                    dy[j] = (float)((const __bf16 *)A.grad_out)[grow + 64 * j];
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    an[j] = A.tok_table[trow + 64 * j];
+                    dy[j] = A.grad_out[grow + 64 * j];
+                }
+            }
+            if (MODE == MOT_MIX_SUM) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
+                    idj[j] = __shfl(ida, sl, 64);
+                    const int64_t o1 = (int64_t)idj[j] * A.Db + wi;
+                    float v = A.in_bf16 ? (float)((const __bf16 *)A.byte_table)[o1] : A.byte_table[o1];
+                    if (dual) {
+                        const int64_t o2 = (int64_t)__shfl(idb, sl, 64) * A.Db + wi;
+                        v += A.in_bf16 ? (float)((const __bf16 *)A.byte_table)[o2] : A.byte_table[o2];
+                    }
+                    bn[j] = v;
+                }
+            }
+            tok_nx = load_tok(n_nx);
+            if (MODE == MOT_MIX_SUM) { ida_nx = load_id(A.ids_a, n_nx); if (dual) idb_nx = load_id(A.ids_b, n_nx); }
+            float rnb = 1.f;   // lanes < bpt: 1/rms of the slot's byte row
+            if (MODE == MOT_MIX_SUM && A.norm_byte) {
+                rnb = A.byte_rnorm[ida];
+#pragma unroll
+                for (int j = 0; j < NE; ++j) bn[j] *= __shfl(rnb, slw[j] >> 16, 64);
+            }
+            // ---- forward scalars, then back through the output norm
+            float ra = 1.f;
+            if (A.norm_tok) {
+                float ss = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
+                ra = rms_scale(wave_sum(ss), D, A.eps);
+#pragma unroll
+                for (int j = 0; j < NE; ++j) an[j] *= ra;
+            }
+            if (A.norm_out) {
+                float ss = 0.f, m = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const float y = an[j] * s_tok + (MODE == MOT_MIX_SUM ? bn[j] * s_byte : 0.f);
+                    ss += y * y;
+                    m += dy[j] * y;
+                }
+                const float ry = rms_scale(wave_sum(ss), D, A.eps);
+                m = wave_sum(m) * ry / (float)D;       // mean(g * x), x = y * ry
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const float x = (an[j] * s_tok + (MODE == MOT_MIX_SUM ? bn[j] * s_byte : 0.f)) * ry;
+                    dy[j] = ry * (dy[j] - x * m);
+                }
+            }
+            // ---- token side
+            {
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) dot += dy[j] * an[j];
+                ds_t += dot;
+                float mt = 0.f;
+                if (A.norm_tok) mt = wave_sum(dot * s_tok) / (float)D;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const float da = dy[j] * s_tok;
+                    acc[j] += A.norm_tok ? ra * (da - an[j] * mt) : da;
+                }
+            }
+            // ---- byte side
+            if (MODE == MOT_MIX_SUM) {
+                float dot = 0.f, vmax = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) { dot += dy[j] * bn[j]; dy[j] *= s_byte; }
+                ds_b += dot;
+                if (A.norm_byte) {   // v = r_row * (db - b_n * mean_slot(db * b_n)): per-slot sums in fixed point
+                    float pmax = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) pmax = fmaxf(pmax, fabsf(dy[j] * bn[j]));
+                    pmax = wave_max(pmax);
+                    const int kk = (pmax > 0.f && pmax < INFINITY) ? 40 - ilogbf(pmax) : 0;
+                    // every lane takes part in the zeroing and the read-back (kMaxBpt = 64 entries): with a
+                    // `lane < bpt` guard the compiler sinks the atomics into both sides of the branch and the
+                    // unguarded lanes' adds run BEFORE the zeroing store
+                    seg_q[lane] = 0ull;
+                    __threadfence_block();
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) atomicAdd(seg_q + (slw[j] >> 16), to_fixed(dy[j] * bn[j], kk));
+                    __threadfence_block();
+                    float sg = (float)ldexp((double)(long long)seg_q[lane], -kk) / (float)A.Db;
+                    if (!(pmax < INFINITY)) sg = NAN;   // non-finite gradients stay non-finite
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const int sl = slw[j] >> 16;
+                        dy[j] = __shfl(rnb, sl, 64) * (dy[j] - bn[j] * __shfl(sg, sl, 64));
+                    }
+                    __threadfence_block();
+                }
+                if (fx_pending) {   // once per wave: agree on the workgroup's fixed-point scale (see embed_mix_bwd_kernel)
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) vmax = fmaxf(vmax, fabsf(dy[j]));
+                    vmax = wave_max(vmax);
+                    if (lane == 0 && vmax > 0.f && vmax < INFINITY) atomicMax(fx_bits, __float_as_uint(vmax));
+                    __syncthreads();
+                    const float m = __uint_as_float(*fx_bits);
+                    fx_k = m > 0.f ? 28 - ilogbf(m) : 0;
+                    fx_hi = ldexpf(1.0f, 40 - fx_k);
+                    fx_pending = false;
+                }
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
+                    const float v = dy[j];
+                    const int s1 = byte_slot(idj[j]);
+                    if (s1 >= 0 && fabsf(v) < fx_hi) atomicAdd(dbyte_q + s1 * A.Db + wi, to_fixed(v, fx_k));
+                    else atomicAdd(A.d_byte + idj[j] * A.Db + wi, v);
+                    if (dual) {
+                        const int id2 = __shfl(idb, sl, 64), s2 = byte_slot(id2);
+                        if (s2 >= 0 && fabsf(v) < fx_hi) atomicAdd(dbyte_q + s2 * A.Db + wi, to_fixed(v, fx_k));
+                        else atomicAdd(A.d_byte + id2 * A.Db + wi, v);
+                    }
+                }
+            }
+        }
+    }
+    flush();
+    if (A.d_scale_tok) { ds_t = wave_sum(ds_t); if (lane == 0) atomicAdd(A.d_scale_tok, ds_t); }
+    if (MODE == MOT_MIX_SUM && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
+    if (MODE == MOT_MIX_SUM) {
+        if (fx_pending) {
+            __syncthreads();
+            const float m = __uint_as_float(*fx_bits);
+            fx_k = m > 0.f ? 28 - ilogbf(m) : 0;
+        }
+        __syncthreads();
+        for (int i = tid; i < nbyte; i += kBwdThreads) {
+            const long long q = (long long)dbyte_q[i];
+            if (q == 0) continue;
+            const int sl = i / A.Db, wi = i - sl * A.Db;
+            const int row = sl < A.priv_lo ? sl : sl - A.priv_lo + A.priv_hi0;
+            atomicAdd(A.d_byte + row * A.Db + wi, (float)ldexp((double)q, -fx_k));
         }
     }
 }
@@ -334,6 +618,44 @@ static int launch_bwd(const BwdArgs &A, size_t lds, hipStream_t stream) {
     return check_launch("embed_mix_bwd_kernel");
 }
 
+template <int MODE, int NE>
+static int launch_bwd_full(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_bwd_full_kernel<MODE, NE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_bwd_full_kernel): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    int64_t blocks = ((A.n_tokens + kWindow - 1) / kWindow + kBwdWaves - 1) / kBwdWaves;
+    if (blocks > 256) blocks = 256;
+    hipLaunchKernelGGL((embed_mix_bwd_full_kernel<MODE, NE>), dim3((unsigned)blocks), dim3(kBwdThreads), lds, stream, A);
+    return check_launch("embed_mix_bwd_full_kernel");
+}
+
+// rows that are "full" (see embed_mix_bwd_full_kernel): SUM / NOOP, D a multiple of 64 with a built NE
+template <int MODE>
+static bool full_layout(const BwdArgs &A) {
+    if (MODE == MOT_MIX_CONCAT_LINEAR || (A.D & 63) || A.Dt != A.D || A.tok_lo != 0) return false;
+    if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D || A.Db > 0xffff)) return false;
+    if (A.abl) return false;
+    const int ne = A.D / 64;
+    return ne == 1 || ne == 2 || ne == 4 || ne == 8 || ne == 12 || ne == 16 || ne == 24 || ne == 32;
+}
+
+template <int MODE>
+static int dispatch_ne_full(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    switch (A.D / 64) {
+        case 1: return launch_bwd_full<MODE, 1>(A, lds, stream);
+        case 2: return launch_bwd_full<MODE, 2>(A, lds, stream);
+        case 4: return launch_bwd_full<MODE, 4>(A, lds, stream);
+        case 8: return launch_bwd_full<MODE, 8>(A, lds, stream);
+        case 12: return launch_bwd_full<MODE, 12>(A, lds, stream);
+        case 16: return launch_bwd_full<MODE, 16>(A, lds, stream);
+        case 24: return launch_bwd_full<MODE, 24>(A, lds, stream);
+        default: return launch_bwd_full<MODE, 32>(A, lds, stream);
+    }
+}
+
 template <int MODE>
 static int dispatch_ne(const BwdArgs &A, size_t lds, hipStream_t stream) {
     const int ne = (A.D + 63) / 64;
@@ -373,16 +695,23 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     if (getenv("MOT_BWD_ABL")) A.abl = atoi(getenv("MOT_BWD_ABL"));
     if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
 #endif
-    size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float);
-    A.privatize = 0;
+    size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
+    A.priv_lo = 0; A.priv_hi0 = (int)d.byte_rows; A.priv_rows = 0;
     if (MODE != MOT_MIX_NOOP) {
-        const size_t tab = (size_t)d.byte_rows * d.byte_dim * sizeof(float);
-        if (tab + lds <= 150 * 1024) { A.privatize = 1; lds += tab; }
+        // as many byte-table rows as 150 KiB of LDS hold at 8 bytes per element; when not all fit, the last 32 rows
+        // (pad / eot and other specials sit at the end of the byte vocabulary) and the first cap-32
+        const int64_t cap = (int64_t)((150 * 1024 - lds) / ((size_t)d.byte_dim * 8));
+        if (cap >= d.byte_rows) { A.priv_lo = (int)d.byte_rows; A.priv_rows = (int)d.byte_rows; }
+        else if (cap > 64) { A.priv_lo = (int)cap - 32; A.priv_hi0 = (int)d.byte_rows - 32; A.priv_rows = (int)cap; }
+        lds += (size_t)A.priv_rows * d.byte_dim * 8;
         if (d.norm_byte && !(MODE == MOT_MIX_CONCAT_LINEAR && d.ids_b)) {
             rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rnorm_ws, A.in_bf16 ? MOT_BF16 : MOT_F32, stream);
             if (rc) return rc;
             A.byte_rnorm = rnorm_ws;
         }
+    }
+    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
+        if (full_layout<MODE>(A)) return dispatch_ne_full<MODE>(A, lds, stream);
     }
     return dispatch_ne<MODE>(A, lds, stream);
 }
