@@ -58,6 +58,7 @@ struct BwdArgs {
     // byte-table gradient privatised in LDS as 64-bit fixed point: rows [0, priv_lo) and [priv_hi0, byte_rows) have a slot
     // (everything when the table fits; otherwise the raw byte values and the trailing specials such as pad / eot)
     int priv_lo, priv_hi0, priv_rows;
+    int chunk;  // embed_mix_bwd_full_kernel: positions per LDS-sorted chunk (power of two <= kChunkMax)
     const int32_t *pos_sorted;  // token positions ordered by token id
     int in_bf16;  // tables and grad_out are bf16 (gradients are accumulated and returned in fp32 either way)
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
@@ -346,6 +347,8 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, int k) {
     return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
 }
 
+constexpr int kChunkMax = 2048;   // positions one workgroup sorts in LDS at a time (11 index bits next to the token id)
+
 template <int MODE, int NE>
 __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const BwdArgs A) {
     constexpr int D = 64 * NE;
@@ -355,9 +358,9 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     unsigned long long *dbyte_q = lds_q;
     unsigned long long *seg_q = lds_q + nbyte + wave * kMaxBpt;                      // per-wave per-slot sums (byte-norm backward)
     uint32_t *fx_bits = (uint32_t *)(lds_q + nbyte + kBwdWaves * kMaxBpt);
+    uint32_t *skey = fx_bits + 4;                                                    // [chunk] (token << 11 | index in chunk), sorted
     for (int i = tid; i < nbyte; i += kBwdThreads) dbyte_q[i] = 0ull;
     if (tid == 0) *fx_bits = 0u;
-    __syncthreads();
     const bool dual = MODE == MOT_MIX_SUM && A.ids_b != nullptr;
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
@@ -368,10 +371,19 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
         const int e = lane + 64 * j, sl = MODE == MOT_MIX_SUM ? e / A.Db : 0;
         slw[j] = (sl << 16) | (e - sl * A.Db);
     }
+    // fixed-point scale of the privatised byte-table sums (see embed_mix_bwd_kernel): chosen per workgroup from the
+    // upstream gradient rows of the waves' first positions, v * 2^fx_k with the sample's max |g * scale_byte| at 2^24.
+    // Terms that would land outside [2^12, 2^40) -- and rows without a slot -- take the exact global atomic.
     int fx_k = 0;
-    float fx_hi = 0.f;      // |v| at or above this (or non-finite) takes the exact global atomic
-    bool fx_pending = MODE != MOT_MIX_NOOP;
+    float fx_hi = 0.f, fx_lo = 0.f;
+    bool fx_known = MODE != MOT_MIX_SUM;
     auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
+    auto add_byte = [&](int id, int wi, float v) {
+        const int sl = byte_slot(id);
+        const float av = fabsf(v);
+        if (sl >= 0 && av < fx_hi && (av >= fx_lo || av == 0.f)) atomicAdd(dbyte_q + sl * A.Db + wi, to_fixed(v, fx_k));
+        else atomicAdd(A.d_byte + id * A.Db + wi, v);
+    };
 
     float acc[NE];
     int cur = -1;
@@ -381,14 +393,6 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
 #pragma unroll
         for (int j = 0; j < NE; ++j) atomicAdd(drow + 64 * j, acc[j]);
     };
-    auto load_tok = [&](int64_t n) {
-        int t = A.tokens[n];
-        if ((uint64_t)(uint32_t)t >= (uint64_t)A.tok_rows) {
-            if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
-            t = 0;
-        }
-        return t;
-    };
     auto load_id = [&](const int64_t *ids, int64_t n) {   // lanes < bpt: the token's byte ids, clamped once
         int64_t v = 0;
         if (lane < A.bpt) {
@@ -397,17 +401,63 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
         }
         return (int)v;
     };
-    const int64_t nwin = (A.n_tokens + kWindow - 1) / kWindow;
-    for (int64_t w = (int64_t)blockIdx.x * kBwdWaves + wave; w < nwin; w += (int64_t)gridDim.x * kBwdWaves) {
-        const int64_t s_end = min(A.n_tokens, (w + 1) * kWindow);
-        int64_t n_nx = A.pos_sorted[w * kWindow];
-        int tok_nx = load_tok(n_nx);
+    const int chunk = A.chunk, per_wave = chunk / kBwdWaves;
+    const int64_t nchunks = (A.n_tokens + chunk - 1) / chunk;
+    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        // ---- group this chunk's positions by token id: bitonic sort of (token << 11 | index) in LDS.  Equal tokens
+        // become runs, so a run costs one atomic row-add; no global histogram / scan / scatter, no sorted index in HBM.
+        const int64_t base = c * chunk;
+        __syncthreads();   // the previous chunk's keys are no longer read (also orders the table zeroing above)
+        for (int i = tid; i < chunk; i += kBwdThreads) {
+            uint32_t key = 0xffffffffu;
+            if (base + i < A.n_tokens) {
+                uint32_t t = (uint32_t)A.tokens[base + i];
+                if ((uint64_t)t >= (uint64_t)A.tok_rows) { if (A.status) atomicOr(A.status, kStatusTokenOor); t = 0; }
+                key = (t << 11) | (uint32_t)i;
+            }
+            skey[i] = key;
+        }
+        __syncthreads();
+        for (int k = 2; k <= chunk; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int p = tid; p < chunk / 2; p += kBwdThreads) {
+                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+                    const uint32_t x = skey[i], y = skey[ixj];
+                    if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[ixj] = x; }
+                }
+                __syncthreads();
+            }
+        const int s_begin = wave * per_wave, s_end = s_begin + per_wave;
+        if (!fx_known) {   // uniform: every wave takes part, once per workgroup
+            const uint32_t key = skey[s_begin];
+            float gmax = 0.f;
+            if (key != 0xffffffffu) {
+                const int64_t grow = (base + (key & 2047)) * D + lane;
+#pragma unroll
+                for (int j = 0; j < NE; ++j)
+                    gmax = fmaxf(gmax, fabsf(A.in_bf16 ? (float)((const __bf16 *)A.grad_out)[grow + 64 * j] : A.grad_out[grow + 64 * j]));
+                gmax = wave_max(gmax) * fabsf(s_byte);
+                if (lane == 0 && gmax > 0.f && gmax < INFINITY) atomicMax(fx_bits, __float_as_uint(gmax));
+            }
+            __syncthreads();
+            const float m = __uint_as_float(*fx_bits);
+            fx_k = m > 0.f ? 24 - ilogbf(m) : 0;
+            fx_hi = ldexpf(1.0f, 40 - fx_k);
+            fx_lo = ldexpf(1.0f, 12 - fx_k);
+            fx_known = true;
+        }
+        uint32_t key_nx = skey[s_begin];
         int ida_nx = 0, idb_nx = 0;
-        if (MODE == MOT_MIX_SUM) { ida_nx = load_id(A.ids_a, n_nx); if (dual) idb_nx = load_id(A.ids_b, n_nx); }
-        for (int64_t si = w * kWindow; si < s_end; ++si) {
-            const int64_t n = n_nx;
-            const int tok = tok_nx, ida = ida_nx, idb = idb_nx;
-            n_nx = A.pos_sorted[min(si + 1, s_end - 1)];
+        if (MODE == MOT_MIX_SUM && key_nx != 0xffffffffu) {
+            ida_nx = load_id(A.ids_a, base + (key_nx & 2047));
+            if (dual) idb_nx = load_id(A.ids_b, base + (key_nx & 2047));
+        }
+        for (int si = s_begin; si < s_end; ++si) {
+            const uint32_t key = key_nx;
+            if (key == 0xffffffffu) break;   // padding of the last chunk sorts to the end
+            const int64_t n = base + (key & 2047);
+            const int tok = (int)(key >> 11), ida = ida_nx, idb = idb_nx;
+            key_nx = si + 1 < s_end ? skey[si + 1] : 0xffffffffu;
             if (tok != cur) {
                 flush();
                 cur = tok;
@@ -443,9 +493,11 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     }
                     bn[j] = v;
                 }
+                if (key_nx != 0xffffffffu) {   // the next position's byte ids while this one's rows are in flight
+                    ida_nx = load_id(A.ids_a, base + (key_nx & 2047));
+                    if (dual) idb_nx = load_id(A.ids_b, base + (key_nx & 2047));
+                }
             }
-            tok_nx = load_tok(n_nx);
-            if (MODE == MOT_MIX_SUM) { ida_nx = load_id(A.ids_a, n_nx); if (dual) idb_nx = load_id(A.ids_b, n_nx); }
             float rnb = 1.f;   // lanes < bpt: 1/rms of the slot's byte row
             if (MODE == MOT_MIX_SUM && A.norm_byte) {
                 rnb = A.byte_rnorm[ida];
@@ -494,7 +546,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
             }
             // ---- byte side
             if (MODE == MOT_MIX_SUM) {
-                float dot = 0.f, vmax = 0.f;
+                float dot = 0.f;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) { dot += dy[j] * bn[j]; dy[j] *= s_byte; }
                 ds_b += dot;
@@ -521,29 +573,11 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     }
                     __threadfence_block();
                 }
-                if (fx_pending) {   // once per wave: agree on the workgroup's fixed-point scale (see embed_mix_bwd_kernel)
-#pragma unroll
-                    for (int j = 0; j < NE; ++j) vmax = fmaxf(vmax, fabsf(dy[j]));
-                    vmax = wave_max(vmax);
-                    if (lane == 0 && vmax > 0.f && vmax < INFINITY) atomicMax(fx_bits, __float_as_uint(vmax));
-                    __syncthreads();
-                    const float m = __uint_as_float(*fx_bits);
-                    fx_k = m > 0.f ? 28 - ilogbf(m) : 0;
-                    fx_hi = ldexpf(1.0f, 40 - fx_k);
-                    fx_pending = false;
-                }
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
-                    const float v = dy[j];
-                    const int s1 = byte_slot(idj[j]);
-                    if (s1 >= 0 && fabsf(v) < fx_hi) atomicAdd(dbyte_q + s1 * A.Db + wi, to_fixed(v, fx_k));
-                    else atomicAdd(A.d_byte + idj[j] * A.Db + wi, v);
-                    if (dual) {
-                        const int id2 = __shfl(idb, sl, 64), s2 = byte_slot(id2);
-                        if (s2 >= 0 && fabsf(v) < fx_hi) atomicAdd(dbyte_q + s2 * A.Db + wi, to_fixed(v, fx_k));
-                        else atomicAdd(A.d_byte + id2 * A.Db + wi, v);
-                    }
+                    add_byte(idj[j], wi, dy[j]);
+                    if (dual) add_byte(__shfl(idb, sl, 64), wi, dy[j]);
                 }
             }
         }
@@ -552,11 +586,6 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     if (A.d_scale_tok) { ds_t = wave_sum(ds_t); if (lane == 0) atomicAdd(A.d_scale_tok, ds_t); }
     if (MODE == MOT_MIX_SUM && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
     if (MODE == MOT_MIX_SUM) {
-        if (fx_pending) {
-            __syncthreads();
-            const float m = __uint_as_float(*fx_bits);
-            fx_k = m > 0.f ? 28 - ilogbf(m) : 0;
-        }
         __syncthreads();
         for (int i = tid; i < nbyte; i += kBwdThreads) {
             const long long q = (long long)dbyte_q[i];
@@ -626,8 +655,8 @@ static int launch_bwd_full(const BwdArgs &A, size_t lds, hipStream_t stream) {
         if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_bwd_full_kernel): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    int64_t blocks = ((A.n_tokens + kWindow - 1) / kWindow + kBwdWaves - 1) / kBwdWaves;
-    if (blocks > 256) blocks = 256;
+    int64_t blocks = (A.n_tokens + A.chunk - 1) / A.chunk;
+    if (blocks > 256) blocks = 256;   // one persistent workgroup per CU
     hipLaunchKernelGGL((embed_mix_bwd_full_kernel<MODE, NE>), dim3((unsigned)blocks), dim3(kBwdThreads), lds, stream, A);
     return check_launch("embed_mix_bwd_full_kernel");
 }
@@ -637,7 +666,7 @@ template <int MODE>
 static bool full_layout(const BwdArgs &A) {
     if (MODE == MOT_MIX_CONCAT_LINEAR || (A.D & 63) || A.Dt != A.D || A.tok_lo != 0) return false;
     if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D || A.Db > 0xffff)) return false;
-    if (A.abl) return false;
+    if (A.abl || A.tok_rows > (1 << 20)) return false;   // (token << 11 | index) must stay below the 0xffffffff sentinel
     const int ne = A.D / 64;
     return ne == 1 || ne == 2 || ne == 4 || ne == 8 || ne == 12 || ne == 16 || ne == 24 || ne == 32;
 }
@@ -678,24 +707,36 @@ static size_t scatter_ws_ints(const MotEmbedMixDesc &d) { return 3 * (size_t)d.t
 
 template <int MODE>
 static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, float *rnorm_ws, hipStream_t stream) {
-    int32_t *counts = ws_ints, *cursor = counts + d.tok_rows, *starts = cursor + d.tok_rows, *pos_sorted = starts + d.tok_rows;
-    hipError_t e = hipMemsetAsync(counts, 0, 2 * (size_t)d.tok_rows * sizeof(int32_t), stream);  // counts + cursor
-    if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    int64_t hb = (A.n_tokens + kThreads - 1) / kThreads;
-    if (hb > 2048) hb = 2048;
-    hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts);
-    hipLaunchKernelGGL(bwd_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, A.tok_rows, starts);
-    hipLaunchKernelGGL(bwd_scatter_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows,
-                       starts, cursor, pos_sorted);
-    int rc = check_launch("embed_mix_bwd sort kernels");
-    if (rc) return rc;
-    A.pos_sorted = pos_sorted;
+    int rc;
     A.abl = 0;
 #ifdef MOT_DEV_ABLATION
     if (getenv("MOT_BWD_ABL")) A.abl = atoi(getenv("MOT_BWD_ABL"));
-    if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
 #endif
+    bool full = false;
+    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) full = full_layout<MODE>(A);
     size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
+    if (full) {
+        // the lean kernel groups positions by token inside LDS, chunk by chunk: >= 256 chunks when there are enough tokens
+        int chunk = 256;
+        while (chunk < kChunkMax && (A.n_tokens + chunk - 1) / chunk > 256) chunk <<= 1;
+        A.chunk = chunk;
+        lds += (size_t)chunk * sizeof(uint32_t);
+    } else {
+        int32_t *counts = ws_ints, *cursor = counts + d.tok_rows, *starts = cursor + d.tok_rows, *pos_sorted = starts + d.tok_rows;
+        hipError_t e = hipMemsetAsync(counts, 0, 2 * (size_t)d.tok_rows * sizeof(int32_t), stream);  // counts + cursor
+        if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        int64_t hb = (A.n_tokens + kThreads - 1) / kThreads;
+        if (hb > 2048) hb = 2048;
+        hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts);
+        hipLaunchKernelGGL(bwd_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, A.tok_rows, starts);
+        hipLaunchKernelGGL(bwd_scatter_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows,
+                           starts, cursor, pos_sorted);
+        if ((rc = check_launch("embed_mix_bwd sort kernels"))) return rc;
+        A.pos_sorted = pos_sorted;
+#ifdef MOT_DEV_ABLATION
+        if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
+#endif
+    }
     A.priv_lo = 0; A.priv_hi0 = (int)d.byte_rows; A.priv_rows = 0;
     if (MODE != MOT_MIX_NOOP) {
         // as many byte-table rows as 150 KiB of LDS hold at 8 bytes per element; when not all fit, the last 32 rows
@@ -711,7 +752,7 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
         }
     }
     if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
-        if (full_layout<MODE>(A)) return dispatch_ne_full<MODE>(A, lds, stream);
+        if (full) return dispatch_ne_full<MODE>(A, lds, stream);
     }
     return dispatch_ne<MODE>(A, lds, stream);
 }
