@@ -11,11 +11,17 @@
 // a row of the nn.Linear weight.  So there is no transposed copy and no workspace: the weight is staged
 // row by row exactly as it lies in memory.
 //
-// Geometry: 256 threads (4 waves, one per SIMD), a tile of TM = 32*MT tokens x all Dm columns (complete
-// rows for the post-norm), wave w owning columns [w*NT*32, (w+1)*NT*32).  K is walked in steps of 16
-// with double-buffered LDS (rows padded to 48 bytes: conflict-free ds_read_b128).  At 16x the fp32 MFMA
-// rate this kernel is bound by streaming W from L2 into LDS once per tile, so the tile is as tall as
-// the accumulators allow without spilling (128 tokens up to Dm = 384, 64 tokens above).
+// Geometry: RG row groups x 4 column groups of waves (256*RG threads), a tile of TM = 32*MT*RG tokens x all Dm
+// columns (complete rows for the post-norm); wave (rg, cg) owns rows [rg*32*MT, ..) and columns
+// [cg*NT*32, ..).  K is walked in steps of 16 with double-buffered LDS (rows padded to 48 bytes:
+// conflict-free ds_read_b128).  Measured on config 2 (timing ablations, 64-token tiles, 4 waves, one workgroup per
+// CU): 42 % of the time was outside the K loop (tile index phase, a serial per-token rms pass, 2-byte stores) and
+// the loop waited on L2 -> LDS staging with nothing to overlap; MFMA time was invisible.  Hence: two waves per
+// SIMD (RG = 2) on a 128-token tile -- W is staged half as often per token and a second wave per SIMD covers
+// the staging latency -- and the token rows' rms factors come from a table computed once per call.
+#include <stdlib.h>
+#include <type_traits>
+
 #include "mot_mix.hpp"
 
 namespace mot {
@@ -29,10 +35,12 @@ constexpr int kRowB = 2 * kBK16 + 16;   // bytes per staged row: 32 data + 16 pa
 
 struct LinArgs16 {
     MixArgs M;
-    const __bf16 *W;     // [Dm, K] nn.Linear layout
+    const __bf16 *W;     // step-major slabs [nsteps][DmPad][16] (pack_w_bf16_kernel)
     const __bf16 *bias;  // [Dm] or null
     int K, Dm, bytes_first, dual;
     float *row_rnorm;    // optional [n_rows*T]: the post-norm factor of every row (for the backward)
+    const float *tok_rnorm;  // optional [tok_rows]: 1/rms of every token-table row (norm_tok), computed once per call
+    int abl;             // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no global loads after step 0, 2 no LDS stores, 4 no MFMA, 8 a single K step
 };
 
 __host__ __device__ inline size_t lin16_lds_bytes(int DmPad, int bpt, int tm) {
@@ -41,9 +49,28 @@ __host__ __device__ inline size_t lin16_lds_bytes(int DmPad, int bpt, int tm) {
     return b + tile_lds_bytes(tm, bpt, true);
 }
 
-template <int MT, int NT>
-__global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(const LinArgs16 P) {
-    constexpr int kTM = 32 * MT;
+// W [Dm, K] (nn.Linear layout) -> step-major slabs Wp[step][n < DmPad][16]: one K step of the main kernel then reads
+// one contiguous DmPad*32-byte slab (whole 128-byte lines).  Read straight from W, a step touches 32 bytes of each of
+// the Dm rows -- a quarter of every line it pulls through L2 -- and the kernel ran at the L2 line rate (measured:
+// 0.18 of 0.40 ms stalled on these loads at config 2).  Rows n >= Dm and columns k >= K are zero.
+__global__ __launch_bounds__(kThreads) void pack_w_bf16_kernel(const __bf16 *__restrict__ W, int Dm, int K, int DmPad, int nsteps,
+                                                               __bf16 *__restrict__ Wp) {
+    const int64_t pieces = (int64_t)nsteps * DmPad * kPPR;   // 8-element pieces
+    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < pieces; q += (int64_t)gridDim.x * kThreads) {
+        const int c = (int)(q % kPPR);
+        const int64_t r = q / kPPR;
+        const int n = (int)(r % DmPad), s = (int)(r / DmPad);
+        const int k = s * kBK16 + 8 * c;
+        bf16x8 v = (bf16x8)((__bf16)0.f);
+        if (n < Dm && k < K) v = *(const bf16x8 *)(W + (int64_t)n * K + k);   // K is a multiple of 8
+        *(bf16x8 *)(Wp + q * 8) = v;
+    }
+}
+
+template <int MT, int NT, int RG>
+__global__ __launch_bounds__(kThreads * RG, 1) void embed_mix_linear_bf16_kernel(const LinArgs16 P) {
+    constexpr int kTM = 32 * MT * RG;
+    constexpr int NTHR = kThreads * RG;
     constexpr int DmPad = NT * 128;
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
     const MixArgs &A = P.M;
@@ -65,7 +92,11 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
     const int ntok = (int)min((int64_t)kTM, A.T - t0);
 
     // ---- phase 1: byte ids of the tile
-    if (A.id_source == MOT_IDS_FROM_TTB) {
+    if (P.abl & 16) {
+        for (int i = tid; i < kTM * sv; i += NTHR) { L.ids[i] = 0; L.val[i] = 0; }
+        for (int i = tid; i < kTM; i += NTHR) L.tok[i] = 0;
+        __syncthreads();
+    } else if (A.id_source == MOT_IDS_FROM_TTB) {
         if (A.pull_dir == kPullLeft) phase1_from_ttb<kPullLeft>(A, L, row, t0, ntok);
         else if (A.pull_dir == kPullRight) phase1_from_ttb<kPullRight>(A, L, row, t0, ntok);
         else phase1_from_ttb<kPullNone>(A, L, row, t0, ntok);
@@ -74,7 +105,7 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
     }
 
     // ---- per-segment rms factors (folded into the A operand before it is rounded to bf16)
-    for (int i = tid; i < kTM * SS; i += kThreads) scale[i] = 1.0f;
+    for (int i = tid; i < kTM * SS; i += NTHR) scale[i] = 1.0f;
     if (tid < kTM) {
         int tok = tid < ntok ? L.tok[tid] : 0;
         if ((uint64_t)(uint32_t)tok >= (uint64_t)A.tok_rows) {
@@ -84,8 +115,10 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
         tokc[tid] = tok;
     }
     __syncthreads();
-    if (A.norm_tok) {
-        for (int t = wave; t < ntok; t += kWaves) {
+    if (A.norm_tok && P.tok_rnorm) {
+        for (int t = tid; t < ntok; t += NTHR) scale[t * SS] = P.tok_rnorm[tokc[t]];
+    } else if (A.norm_tok && !(P.abl & 32)) {
+        for (int t = wave; t < ntok; t += kWaves * RG) {
             const __bf16 *trow = tok_table + (int64_t)tokc[t] * A.Dt;
             float ss = 0.f;
             for (int c = lane; c < (A.Dt >> 3); c += 64) {
@@ -98,7 +131,7 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
         }
     }
     if (A.norm_byte) {
-        for (int p = tid; p < ntok * bpt; p += kThreads) {
+        for (int p = tid; p < ntok * bpt; p += NTHR) {
             const int t = p / bpt, k = p - t * bpt;
             const int id = L.ids[t * sv + k];
             float r;
@@ -125,56 +158,67 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     const bool scale_t = A.scale_tok != nullptr, scale_b = A.scale_byte != nullptr;
     const int nbytes_k = bpt * A.Db;
-    constexpr int WP = DmPad * kPPR / kThreads;  // 16-byte pieces of the W chunk per thread
-    constexpr int AP = (kTM * kPPR + kThreads - 1) / kThreads;
-    bf16x8 wreg[WP], areg[AP];
+    constexpr int WP = (DmPad * kPPR + NTHR - 1) / NTHR;  // 16-byte pieces of the W chunk per thread
+    constexpr int AP = (kTM * kPPR + NTHR - 1) / NTHR;
+    // three register sets: the loads of K steps s+1, s+2, s+3 are in flight while step s is multiplied (one step of
+    // 12 MFMAs is ~0.2 us, an L2 round trip under load 1-2 us)
+    constexpr int kSets = 3;
+    bf16x8 wreg[kSets][WP], areg[kSets][AP], areg2[kSets][AP];
+    float afac[kSets][AP];
+    bool atok[kSets][AP];
+    const float inv_db = 1.0f / (float)A.Db;
 
-    auto load_stage = [&](int s) {
+    auto load_stage = [&](int s, auto setc) {
+        constexpr int SET = decltype(setc)::value;
         const int k0 = s * kBK16;
+        const __bf16 *slab = P.W + (int64_t)s * (DmPad * kBK16);
 #pragma unroll
         for (int p = 0; p < WP; ++p) {
-            const int q = p * kThreads + tid, n = q / kPPR, c = q % kPPR;   // row n of W, 8-element piece c of the step
-            const int k = min(k0 + 8 * c, P.K - 8);
-            const int nn = min(n, P.Dm - 1);
-            bf16x8 v = *(const bf16x8 *)(P.W + (int64_t)nn * P.K + k);
-            if (n >= P.Dm || k0 + 8 * c >= P.K) v = (bf16x8)((__bf16)0.f);
-            wreg[p] = v;
+            const int q = min(p * NTHR + tid, DmPad * kPPR - 1);   // piece q of the slab: 16 contiguous bytes (row q / 2, half q % 2)
+            wreg[SET][p] = *(const bf16x8 *)(slab + q * 8);
         }
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const int q = p * kThreads + tid, m = min(q / kPPR, kTM - 1), c = q % kPPR;
+            if (p * NTHR + (tid & ~63) >= kTM * kPPR) continue;   // wave-uniform: only the waves that own A pieces gather
+            const int q = p * NTHR + tid, m = min(q / kPPR, kTM - 1), c = q % kPPR;
             const int amr = min(m, ntok - 1);
             const int kreal = k0 + 8 * c;
             const int k = min(kreal, P.K - 8);
             const bool is_tok = P.bytes_first ? k >= nbytes_k : k < A.Dt;
             const int kb = P.bytes_first ? k : k - A.Dt;
-            const int slot = is_tok ? 0 : kb / A.Db;
+            const int slot = is_tok ? 0 : __float2int_rd(((float)kb + 0.5f) * inv_db);
             const int off = is_tok ? (P.bytes_first ? k - nbytes_k : k) : kb - slot * A.Db;
             const int id1 = L.ids[amr * sv + slot];
             const __bf16 *p1 = is_tok ? tok_table + (int64_t)tokc[amr] * A.Dt + off : byte_table + (int64_t)id1 * A.Db + off;
-            float8v v = Elem<__bf16>::loadv(p1);
-            if (P.dual) {
-                const float8v v2 = Elem<__bf16>::loadv(byte_table + (int64_t)L.val[amr * sv + slot] * A.Db + off);
-                if (!is_tok) v += v2;
-            }
-            v *= scale[amr * SS + (is_tok ? 0 : 1 + slot)];
-            if (is_tok ? scale_t : scale_b) v *= is_tok ? s_tok : s_byte;
-            if (kreal >= P.K) v = (float8v)(0.f);
-            areg[p] = __builtin_convertvector(v, bf16x8);   // the segment as the reference holds it: bf16
+            // raw rows stay packed in registers until store_stage: scaling here would wait for the load at once
+            areg[SET][p] = *(const bf16x8 *)p1;
+            if (P.dual) areg2[SET][p] = *(const bf16x8 *)(byte_table + (int64_t)L.val[amr * sv + slot] * A.Db + off);
+            float f = scale[amr * SS + (is_tok ? 0 : 1 + slot)];
+            if (is_tok ? scale_t : scale_b) f *= is_tok ? s_tok : s_byte;
+            if (kreal >= P.K) f = 0.f;
+            afac[SET][p] = f;
+            atok[SET][p] = is_tok;
         }
     };
-    auto store_stage = [&](int buf) {
+    auto store_stage = [&](int buf, auto setc) {
+        constexpr int SET = decltype(setc)::value;
         char *wb = W0 + (size_t)buf * DmPad * kRowB;
 #pragma unroll
         for (int p = 0; p < WP; ++p) {
-            const int q = p * kThreads + tid, n = q / kPPR, c = q % kPPR;
-            *(bf16x8 *)(wb + n * kRowB + 16 * c) = wreg[p];
+            const int q = p * NTHR + tid, n = q / kPPR, c = q % kPPR;
+            if (n < DmPad) *(bf16x8 *)(wb + n * kRowB + 16 * c) = wreg[SET][p];
         }
         char *ab = A0 + (size_t)buf * kTM * kRowB;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            const int q = p * kThreads + tid, m = q / kPPR, c = q % kPPR;
-            if (m < kTM) *(bf16x8 *)(ab + m * kRowB + 16 * c) = areg[p];
+            const int q = p * NTHR + tid, m = q / kPPR, c = q % kPPR;
+            if (m < kTM) {
+                float8v v = __builtin_convertvector(areg[SET][p], float8v);
+                if (P.dual && !atok[SET][p]) v += __builtin_convertvector(areg2[SET][p], float8v);
+                v *= afac[SET][p];
+                if (afac[SET][p] == 0.f) v = (float8v)(0.f);   // the zero padding of the last step, whatever the clamped load read
+                *(bf16x8 *)(ab + m * kRowB + 16 * c) = __builtin_convertvector(v, bf16x8);   // the segment as the reference holds it: bf16
+            }
         }
     };
 
@@ -187,29 +231,46 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
     const int h = lane >> 5, li = lane & 31;
-    const int n0 = wave * (NT * 32);
-    const int nsteps = (P.K + kBK16 - 1) / kBK16;
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    for (int s = 0; s < nsteps; ++s) {
-        load_stage(min(s + 1, nsteps - 1));
+    const int rg = wave >> 2, cg = wave & 3;       // row group, column group
+    const int m0 = rg * (32 * MT), n0 = cg * (NT * 32);
+    const int nsteps = (P.abl & 8) ? 1 : (P.K + kBK16 - 1) / kBK16;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    // step s: its operands sit in LDS buffer s & 1; register set s % 3 is free (stored during step s-1) and takes the
+    // loads of step s+3; set (s+1) % 3 -- issued two steps ago -- is written to the other buffer after the MFMAs
+    auto step = [&](int s, auto setc, auto setn) {
+        if (!(P.abl & 1)) load_stage(min(s + kSets, nsteps - 1), setc);
         const char *ab = A0 + (size_t)(s & 1) * kTM * kRowB, *wb = W0 + (size_t)(s & 1) * DmPad * kRowB;
 #pragma unroll
         for (int kk = 0; kk < kBK16 / 16; ++kk) {
             bf16x8 af[MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf16x8 *)(ab + (mt * 32 + li) * kRowB + 32 * kk + 16 * h);
+            for (int mt = 0; mt < MT; ++mt) af[mt] = *(const bf16x8 *)(ab + (m0 + mt * 32 + li) * kRowB + 32 * kk + 16 * h);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const bf16x8 bf = *(const bf16x8 *)(wb + (n0 + nt * 32 + li) * kRowB + 32 * kk + 16 * h);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt)
+                    if (!(P.abl & 4)) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mt], bf, acc[mt][nt], 0, 0, 0);
             }
         }
-        store_stage((s + 1) & 1);
+        if (!(P.abl & 2)) store_stage((s + 1) & 1, setn);
         __syncthreads();
+    };
+    load_stage(0, S0{});
+    load_stage(min(1, nsteps - 1), S1{});
+    load_stage(min(2, nsteps - 1), S2{});
+    store_stage(0, S0{});
+    __syncthreads();
+    int s = 0;
+    for (; s + 3 <= nsteps; s += 3) {
+        step(s, S0{}, S1{});
+        step(s + 1, S1{}, S2{});
+        step(s + 2, S2{}, S0{});
     }
+    if (s < nsteps) step(s, S0{}, S1{});
+    if (s + 1 < nsteps) step(s + 1, S1{}, S2{});
 
     // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (P.bias) {
@@ -233,19 +294,19 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
                 for (int nt = 0; nt < NT; ++nt) ss += acc[mt][nt][r] * acc[mt][nt][r];  // padded columns hold 0
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-                if (li == 0) rowss[wave * kTM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = ss;
+                if (li == 0) rowss[cg * kTM + m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = ss;
             }
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const float tot = ((rowss[m] + rowss[kTM + m]) + rowss[2 * kTM + m]) + rowss[3 * kTM + m];
                 const float rs = rms_scale(tot, P.Dm, A.eps);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] *= rs;
-                if (P.row_rnorm && wave == 0 && li == 0 && m < ntok) P.row_rnorm[row * A.T + t0 + m] = rs;
+                if (P.row_rnorm && cg == 0 && li == 0 && m < ntok) P.row_rnorm[row * A.T + t0 + m] = rs;
             }
     }
     __bf16 *orow = (__bf16 *)A.out + (row * A.T + t0) * (int64_t)P.Dm;
@@ -253,8 +314,8 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m < ntok) {
+            const int m = m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m < ntok && !(P.abl & 64)) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int col = n0 + nt * 32 + li;
@@ -264,9 +325,9 @@ __global__ __launch_bounds__(kThreads, 1) void embed_mix_linear_bf16_kernel(cons
         }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int RG>
 static int launch_lin16(LinArgs16 &P, const MotEmbedMixDesc &d, hipStream_t stream) {
-    constexpr int TM = 32 * MT;
+    constexpr int TM = 32 * MT * RG;
     P.M.tile_tokens = TM;
     const int64_t tiles_per_row = (d.tokens_per_row + TM - 1) / TM;
     P.M.tiles_per_row = (int)tiles_per_row;
@@ -277,15 +338,28 @@ static int launch_lin16(LinArgs16 &P, const MotEmbedMixDesc &d, hipStream_t stre
         return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear bf16: needs %zu B of LDS (model_dim %d, bpt %d) > 160 KiB", lds, P.Dm, P.M.bpt);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_bf16_kernel<MT, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_bf16_kernel<MT, NT, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_linear_bf16_kernel): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    hipLaunchKernelGGL((embed_mix_linear_bf16_kernel<MT, NT>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, P);
+    hipLaunchKernelGGL((embed_mix_linear_bf16_kernel<MT, NT, RG>), dim3((unsigned)blocks), dim3(kThreads * RG), lds, stream, P);
     return check_launch("embed_mix_linear_bf16_kernel");
 }
 
-size_t embed_mix_linear_bf16_workspace_bytes(const MotEmbedMixDesc &d) { return d.norm_byte ? (size_t)d.byte_rows * sizeof(float) : 0; }
+// workspace: [byte-row rms factors: byte_rows (norm_byte)][token-row rms factors: tok_rows (norm_tok)][packed W]
+static size_t ws_byte_floats(const MotEmbedMixDesc &d) { return d.norm_byte ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
+static size_t ws_tok_floats(const MotEmbedMixDesc &d) { return d.norm_tok ? ((size_t)d.tok_rows + 3) & ~(size_t)3 : 0; }
+static int nt_of16(int Dm) {   // column tiles of 128 per workgroup, as dispatched below
+    const int nt = (Dm + 127) / 128;
+    return nt == 5 ? 6 : (nt == 7 ? 8 : nt);
+}
+static size_t ws_packed_w_bytes(const MotEmbedMixDesc &d) {
+    const int K = d.tok_dim + d.bpt * d.byte_dim, nsteps = (K + kBK16 - 1) / kBK16, DmPad = nt_of16(d.model_dim) * 128;
+    return (size_t)nsteps * DmPad * kBK16 * 2;
+}
+size_t embed_mix_linear_bf16_workspace_bytes(const MotEmbedMixDesc &d) {
+    return (ws_byte_floats(d) + ws_tok_floats(d)) * sizeof(float) + ws_packed_w_bytes(d);
+}
 
 int launch_embed_mix_linear_bf16(const MotEmbedMixDesc &d, hipStream_t stream) {
     if (d.model_dim > 1024) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear bf16: model_dim %d > 1024 is not built", d.model_dim);
@@ -297,27 +371,45 @@ int launch_embed_mix_linear_bf16(const MotEmbedMixDesc &d, hipStream_t stream) {
     P.Dm = d.model_dim;
     P.bytes_first = d.bytes_first;
     P.dual = d.id_source == MOT_IDS_FROM_TTB ? d.add_padded != 0 : d.ids_b != nullptr;
-    P.W = (const __bf16 *)d.weight;
     P.bias = (const __bf16 *)d.bias;
     P.row_rnorm = d.norm_out ? d.out_row_rnorm : nullptr;
+    P.abl = 0;
+#ifdef MOT_DEV_ABLATION
+    if (getenv("MOT_LIN16_ABL")) P.abl = atoi(getenv("MOT_LIN16_ABL"));
+#endif
+    const size_t need = embed_mix_linear_bf16_workspace_bytes(d);
+    if (need && (!d.workspace || d.workspace_bytes < need))
+        return set_error(MOT_EWORKSPACE, "embed_mix concat_linear bf16: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
     if (d.norm_byte && !P.dual) {
-        const size_t need = (size_t)d.byte_rows * sizeof(float);
-        if (!d.workspace || d.workspace_bytes < need)
-            return set_error(MOT_EWORKSPACE, "embed_mix concat_linear bf16: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
         int rc = launch_rows_rnorm(d.byte_table, d.byte_rows, d.byte_dim, P.M.eps, (float *)d.workspace, MOT_BF16, stream);
         if (rc) return rc;
         P.M.byte_rnorm = (const float *)d.workspace;
     }
+    P.tok_rnorm = nullptr;
+    if (d.norm_tok) {   // one pass over the token table (L2 / HBM streaming) instead of a dependent row fetch per token per tile
+        float *tr = (float *)d.workspace + ws_byte_floats(d);
+        int rc = launch_rows_rnorm(d.tok_table, d.tok_rows, d.tok_dim, P.M.eps, tr, MOT_BF16, stream);
+        if (rc) return rc;
+        P.tok_rnorm = tr;
+    }
+    {
+        const int nsteps = (P.K + kBK16 - 1) / kBK16, DmPad = nt_of16(d.model_dim) * 128;
+        __bf16 *wp = (__bf16 *)((float *)d.workspace + ws_byte_floats(d) + ws_tok_floats(d));
+        hipLaunchKernelGGL(pack_w_bf16_kernel, dim3(256), dim3(kThreads), 0, stream, (const __bf16 *)d.weight, d.model_dim, P.K, DmPad, nsteps, wp);
+        int rc = check_launch("pack_w_bf16_kernel");
+        if (rc) return rc;
+        P.W = wp;
+    }
     const int nt = (d.model_dim + 127) / 128;
     // the tallest tile whose accumulators (MT*NT*16 registers) and LDS image still fit
+    // 8 waves (two per SIMD, 256 registers each): 128-token tiles while 2*NT*16 accumulators fit, 64 tokens at NT = 8
     switch (nt) {
-        case 1: return launch_lin16<4, 1>(P, d, stream);
-        case 2: return launch_lin16<4, 2>(P, d, stream);
-        case 3: return launch_lin16<4, 3>(P, d, stream);
-        case 4: return launch_lin16<2, 4>(P, d, stream);
-        case 5:
-        case 6: return launch_lin16<2, 6>(P, d, stream);
-        default: return launch_lin16<2, 8>(P, d, stream);
+        case 1: return launch_lin16<2, 1, 2>(P, d, stream);
+        case 2: return launch_lin16<2, 2, 2>(P, d, stream);
+        case 3: return launch_lin16<2, 3, 2>(P, d, stream);
+        case 4: return launch_lin16<1, 4, 2>(P, d, stream);
+        case 6: return launch_lin16<1, 6, 2>(P, d, stream);
+        default: return launch_lin16<1, 8, 2>(P, d, stream);
     }
 }
 

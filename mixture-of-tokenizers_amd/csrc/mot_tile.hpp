@@ -223,14 +223,16 @@ __device__ __forceinline__ void tile_scan_and_compact(const Src &src, int64_t t0
     int bnd;
     if (DIR == kPullLeft) bnd = wave_incl_max(e ? tid : -1, lane);
     else bnd = wave_rincl_min(e ? tid : kMaxTileTokens, lane);
-    if (lane == 63) L.misc[wave] = winc;
-    if (DIR == kPullLeft) { if (lane == 63) L.misc[4 + wave] = bnd; }
-    else { if (lane == 0) L.misc[4 + wave] = bnd; }
+    // (a kernel may run these tile passes in a workgroup of more than kThreads threads: the extra waves
+    // hold no token and only meet the barriers)
+    if (lane == 63 && wave < kWaves) L.misc[wave] = winc;
+    if (DIR == kPullLeft) { if (lane == 63 && wave < kWaves) L.misc[4 + wave] = bnd; }
+    else { if (lane == 0 && wave < kWaves) L.misc[4 + wave] = bnd; }
     if (tid == 0) L.cum[0] = 0;
     __syncthreads();
     int incl = winc;
-    for (int w = 0; w < wave; ++w) incl += L.misc[w];
-    if (DIR == kPullLeft) { for (int w = 0; w < wave; ++w) bnd = max(bnd, L.misc[4 + w]); }
+    for (int w = 0; w < min(wave, kWaves); ++w) incl += L.misc[w];
+    if (DIR == kPullLeft) { for (int w = 0; w < min(wave, kWaves); ++w) bnd = max(bnd, L.misc[4 + w]); }
     else { for (int w = wave + 1; w < kWaves; ++w) bnd = min(bnd, L.misc[4 + w]); }
     if (tid < kMaxTileTokens && tid < ntok) L.cum[tid + 1] = incl;
     __syncthreads();
@@ -287,7 +289,7 @@ struct SlotLayout {
     int kq, tq, tstride;
     __device__ __forceinline__ explicit SlotLayout(int bpt) {
         const int bp2 = bpt <= 1 ? 1 : 1 << (32 - __builtin_clz(bpt - 1));
-        kq = threadIdx.x & (bp2 - 1);
+        kq = threadIdx.x < kThreads ? (int)(threadIdx.x & (bp2 - 1)) : 1 << 20;   // threads beyond kThreads idle
         tq = threadIdx.x / bp2;
         tstride = kThreads / bp2;
     }

@@ -105,3 +105,29 @@ def create_batch(tokens: torch.Tensor, bytes_per_token: int, pad_byte: int, eot_
     tl, tr = _table_of(tokens_to_bytes_left_pad), _table_of(tokens_to_bytes_right_pad)
     assert tl.shape[1] == bytes_per_token
     return F_mot.create_batch(tokens, tl, tr, pad_byte, eot_byte)
+
+
+# ------------------------------------------------------------------------------------------------
+# mathblations: token -> digit ids (mathblations/data.py:92-109) is the same gather with an arithmetic table
+# ------------------------------------------------------------------------------------------------
+def make_digit_table(max_digits_per_token: int = 3) -> torch.Tensor:
+    """GenerateEquations.tokens_to_digits as a (vocab_size, max_digits_per_token) int16 table: a numeric token's
+    decimal digits right-aligned, filled with 13; the operator token -> 10, '=' -> 11, the pad token -> 12 in the
+    last slot (data.py:58-60, 96-107; vocab_size = 10**d + 3, data.py:72)."""
+    d = int(max_digits_per_token)
+    assert d > 0, f"max_digits_per_token must be > 0 (got {d})"          # data.py:41
+    n_num = 10 ** d
+    tab = torch.full((n_num + 3, d), 13, dtype=torch.int16)
+    v = torch.arange(n_num, dtype=torch.int64)
+    for i in range(d):                                                      # slot -1-i holds digit i of str(v), if v has it
+        has = v >= 10 ** i if i else torch.ones_like(v, dtype=torch.bool)
+        tab[:n_num, d - 1 - i] = torch.where(has, (v // 10 ** i) % 10, torch.tensor(13)).to(torch.int16)
+    tab[n_num, -1], tab[n_num + 1, -1], tab[n_num + 2, -1] = 10, 11, 12    # op, eq, pad
+    return tab
+
+
+def tokens_to_digits(tokens: torch.Tensor, digit_table: torch.Tensor) -> torch.Tensor:
+    """data.py:92-109 on the device: (T,) -> (T*d,) int64, (B, T) -> (B, T*d); `digit_table` from make_digit_table
+    (moved to the tokens' device by the caller, like the token->byte table)."""
+    out = F_mot.tokens_to_bytes(tokens.to(torch.int32), digit_table)
+    return out.view(-1) if tokens.ndim == 1 else out.view(tokens.shape[0], -1)

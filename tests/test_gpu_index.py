@@ -84,6 +84,17 @@ def test_loader_and_create_batch_golden(dc):
 
 
 # ---- vs the oracle on seeded inputs, including tile-boundary and long-lookback cases
+def test_tokens_to_digits_golden(dc):
+    """mathblations/data.py:92-109, 160-175 on the device: the reference's digit ids for its own equations, bit for bit."""
+    z = np.load(G / "mathblations_c1.npz")
+    tab = dc.make_digit_table(3).to(DEV)
+    got = dc.tokens_to_digits(dev(z["all_tokens"]), tab)
+    assert got.dtype == torch.int64
+    np.testing.assert_array_equal(host(got), z["all_digits"])
+    np.testing.assert_array_equal(host(got)[:, :-3], z["x_digit_tokens"])          # inputs drop the last token's digits
+    np.testing.assert_array_equal(host(dc.tokens_to_digits(dev(z["all_tokens"][0]), tab)), z["all_digits"][0])
+
+
 @pytest.mark.parametrize("bpt,B,T,vocab,seed,eot_p", [
     (16, 8, 2048, 512, 7001, 1 / 700),     # C4-shaped rows (T=2048): 8 tiles per row
     (16, 3, 1000, 512, 7002, 0.02),        # ragged last tile

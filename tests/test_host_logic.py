@@ -56,6 +56,17 @@ def test_rank_slice_and_shift_match_reference_fixture():
         loader.rank_slice(data, pos, batch, seq, 0, 3)      # train_gpt.py:795
 
 
+def test_digit_table_matches_the_reference():
+    """make_digit_table == GenerateEquations.tokens_to_digits applied to every token id (mathblations/data.py:92-109)."""
+    from mixture_of_tokenizers_amd import data_creation as dc
+    z = np.load(G / "mathblations_c1.npz")
+    np.testing.assert_array_equal(dc.make_digit_table(3).numpy(), z["digit_table"])
+    t2 = dc.make_digit_table(2).numpy()              # another width against the oracle's restatement
+    np.testing.assert_array_equal(t2, orc.tokens_to_digits(np.arange(103), 2).reshape(103, 2))
+    with pytest.raises(AssertionError):
+        dc.make_digit_table(0)
+
+
 def test_create_data_dispatch_keys():
     from mixture_of_tokenizers_amd import loader
     from mixture_of_tokenizers_amd.modules import ByteHyperparameters
