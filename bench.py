@@ -135,7 +135,7 @@ def cpu_baseline(wl, inp, seconds):
         elif mode == "concat_linear":
             padded = orc.tokens_to_bytes(toks, inp["tab"].astype(np.float32))
             pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
-            orc.embed_mix(toks, pulled, None, Et, Eb, mode="concat_linear", bpt=bpt, weight=inp["weight"].cpu().numpy(),
+            orc.embed_mix(toks, pulled, None, Et, Eb, mode="concat_linear", bpt=bpt, weight=inp["weight"].float().cpu().numpy(),
                           dtype=np.float32, norm_tok=True, norm_byte=True, norm_out=True)
         else:
             orc.embed_mix(toks, inp["chars"][:rows], None, Et, Eb, mode="mean", bpt=bpt, dtype=np.float32)
