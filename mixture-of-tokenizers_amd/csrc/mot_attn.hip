@@ -151,9 +151,12 @@ static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     L.xkv = take(dual ? T * d.bpt * D : 0);
     L.iota = take(T > (size_t)L.R ? T : (size_t)L.R); L.byte0 = take(4);
     MotEmbedMixDesc g;     // the widest of the GEMMs decides the transposed-weight scratch
-    dense_desc(g, nullptr, nullptr, nullptr, 1, 1, (int)D, nullptr, (int)HD, nullptr, nullptr, nullptr, 0);
+    const int64_t max_rows = d.tok_rows > L.R ? d.tok_rows : L.R;   // the normalising GEMMs keep a per-row rms table in the scratch
+    dense_desc(g, nullptr, nullptr, nullptr, max_rows, 1, (int)D, nullptr, (int)HD, nullptr, nullptr, nullptr, 0);
+    g.norm_tok = 1;
     size_t a = embed_mix_linear_workspace_bytes(g);
-    dense_desc(g, nullptr, nullptr, nullptr, 1, 1, (int)HD, nullptr, (int)D, nullptr, nullptr, nullptr, 0);
+    dense_desc(g, nullptr, nullptr, nullptr, max_rows, 1, (int)HD, nullptr, (int)D, nullptr, nullptr, nullptr, 0);
+    g.norm_tok = 1;
     size_t b = embed_mix_linear_workspace_bytes(g);
     L.lin_floats = ((a > b ? a : b) + 3) / 4;
     L.lin = take(L.lin_floats);

@@ -33,6 +33,7 @@ struct LinArgs {
     const float *Wt;    // [Kpad, DmPad] k-major copy of the weight, zero padded
     const float *bias;  // [Dm] or null
     float *row_rnorm;   // optional [n_rows*T]: the post-norm factor of every row (for the backward)
+    const float *tok_rnorm;  // optional [tok_rows]: 1/rms of every token-table row (norm_tok), computed once per call
     int K, Kpad, Dm, DmPad, bytes_first, dual;
 };
 
@@ -116,7 +117,9 @@ __global__ __launch_bounds__(kThreads, OCC) void embed_mix_linear_kernel(const L
         S.tokc[tid] = tok;
     }
     __syncthreads();
-    if (A.norm_tok) {
+    if (A.norm_tok && P.tok_rnorm) {   // table computed once per call: no dependent row fetch per token per tile
+        for (int t = tid; t < ntok; t += kThreads) S.scale[t * SS] = P.tok_rnorm[S.tokc[t]];
+    } else if (A.norm_tok) {
         for (int t = wave; t < ntok; t += kWaves) {
             const float *trow = A.tok_table + (int64_t)S.tokc[t] * A.Dt;
             float ss = 0.f;
@@ -157,6 +160,8 @@ __global__ __launch_bounds__(kThreads, OCC) void embed_mix_linear_kernel(const L
     const int am = tid % kTM, akq = tid / kTM;  // A staging role: token am, float4 (akq mod kBK/4) of the K-step
     const int nbytes_k = bpt * A.Db;
     float4v wreg[WP], areg;
+    float afac;   // factor of the staged A piece, applied when it is written to LDS: scaling at load time would wait for the load
+    const float inv_db = 1.0f / (float)A.Db;
 
     // Rows past the tile's end read token/byte id 0 (valid memory; never stored); K-padding columns
     // meet zero rows of Wt.  Branch-free on purpose: the K loop body must stay one basic block so
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(kThreads, OCC) void embed_mix_linear_kernel(const L
         const int k = min(k0 + 4 * (akq & (kBK / 4 - 1)), P.K - 4);
         const bool is_tok = P.bytes_first ? k >= nbytes_k : k < A.Dt;
         const int kb = P.bytes_first ? k : k - A.Dt;             // offset inside the byte part
-        const int slot = is_tok ? 0 : kb / A.Db;
+        const int slot = is_tok ? 0 : __float2int_rd(((float)kb + 0.5f) * inv_db);   // kb / Db without the integer division
         const int off = is_tok ? (P.bytes_first ? k - nbytes_k : k) : kb - slot * A.Db;
         const int id1 = L.ids[amr * sv + slot];
         const float *p1 = is_tok ? A.tok_table + (int64_t)tok_m * A.Dt + off : A.byte_table + (int64_t)id1 * A.Db + off;
@@ -180,10 +185,11 @@ __global__ __launch_bounds__(kThreads, OCC) void embed_mix_linear_kernel(const L
             const float4v v2 = *(const float4v *)(A.byte_table + (int64_t)L.val[amr * sv + slot] * A.Db + off);
             v += is_tok ? (float4v)(0.f) : v2;
         }
-        v *= S.scale[amr * SS + (is_tok ? 0 : 1 + slot)];
+        float f = S.scale[amr * SS + (is_tok ? 0 : 1 + slot)];
         const float sc = is_tok ? s_tok : s_byte;
-        if (is_tok ? scale_t : scale_b) v *= sc;
+        if (is_tok ? scale_t : scale_b) f *= sc;
         areg = v;
+        afac = f;
     };
     auto store_stage = [&](int buf) {
         float4v *dst = (float4v *)(S.W0 + buf * (kBK * P.DmPad));
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(kThreads, OCC) void embed_mix_linear_kernel(const L
         for (int p = 0; p < WP; ++p) dst[p * kThreads + tid] = wreg[p];
         // k-major A[k][m]; with kBK == 8 waves 2-3 duplicate the writes of waves 0-1 (same values)
         float *a = S.A0 + buf * (kBK * kTM) + (4 * (akq & (kBK / 4 - 1))) * kTM + am;
-        a[0] = areg.x; a[kTM] = areg.y; a[2 * kTM] = areg.z; a[3 * kTM] = areg.w;
+        a[0] = areg.x * afac; a[kTM] = areg.y * afac; a[2 * kTM] = areg.z * afac; a[3 * kTM] = areg.w * afac;
     };
 
     f32x16 acc[MT][NT];
@@ -349,7 +355,7 @@ size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d) {
     if (nt < 0) return 0;
     const int K = d.tok_dim + d.bpt * d.byte_dim;
     const size_t Kpad = (size_t)(K + kBKmax - 1) / kBKmax * kBKmax, DmPad = (size_t)nt * 128;
-    return (Kpad * DmPad + (size_t)d.byte_rows) * sizeof(float);
+    return (Kpad * DmPad + (((size_t)d.byte_rows + 3) & ~(size_t)3) + (d.norm_tok ? (size_t)d.tok_rows : 0)) * sizeof(float);
 }
 
 template <int MT, int NT, int BK, int OCC = 1, int ABL = 0>
@@ -392,6 +398,7 @@ int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuil
     P.dual = d.id_source == MOT_IDS_FROM_TTB ? d.add_padded != 0 : d.ids_b != nullptr;
     P.bias = (const float *)d.bias;
     P.row_rnorm = d.norm_out ? d.out_row_rnorm : nullptr;
+    P.tok_rnorm = nullptr;
     int rc;
     float *rn = nullptr;
     if (wt_prebuilt) {
@@ -412,6 +419,12 @@ int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuil
         rc = launch_rows_rnorm(P.M.byte_table, d.byte_rows, d.byte_dim, P.M.eps, rn, MOT_F32, stream);
         if (rc) return rc;
         P.M.byte_rnorm = rn;
+    }
+    if (d.norm_tok && rn) {   // one streaming pass over the token table instead of a dependent row fetch per token per tile
+        float *tr = rn + (((size_t)d.byte_rows + 3) & ~(size_t)3);
+        rc = launch_rows_rnorm(P.M.tok_table, d.tok_rows, d.tok_dim, P.M.eps, tr, MOT_F32, stream);
+        if (rc) return rc;
+        P.tok_rnorm = tr;
     }
     // 64-token tiles while the accumulators (2*NT*16 registers) leave room for the partial sums in the
     // 256 architectural VGPRs; the 1024-column variant runs 32-token tiles instead.
