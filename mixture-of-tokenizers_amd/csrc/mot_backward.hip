@@ -361,22 +361,34 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     uint32_t *skey = fx_bits + 4;                                                    // [chunk] (token << 11 | index in chunk), sorted
     for (int i = tid; i < nbyte; i += kBwdThreads) dbyte_q[i] = 0ull;
     if (tid == 0) *fx_bits = 0u;
-    const bool dual = MODE == MOT_MIX_SUM && A.ids_b != nullptr;
+    // SPLIT: the gradient row is du of CONCAT_LINEAR -- [token part | byte part] (or the reverse), every 64-element
+    // chunk j belonging wholly to one part (host-checked); SUM / NOOP rows are token part and byte part at once.
+    constexpr bool SPLIT = MODE == MOT_MIX_CONCAT_LINEAR;
+    constexpr bool BYTES = MODE != MOT_MIX_NOOP;
+    uint32_t tmask = 0, bmask = 0;   // bit j: chunk j carries token-row / byte-row elements
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        const int e0 = 64 * j;
+        if (!SPLIT || (e0 >= A.tok_lo && e0 < A.tok_lo + A.Dt)) tmask |= 1u << j;
+        if (MODE == MOT_MIX_SUM || (SPLIT && e0 >= A.byte_lo && e0 < A.byte_lo + A.nbk)) bmask |= 1u << j;
+    }
+    const bool dual = BYTES && A.ids_b != nullptr;
+    const bool pair_norm = SPLIT && dual && A.norm_byte;   // norm(emb(padded) + emb(pulled)), train_gpt.py:378
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     float ds_t = 0.f, ds_b = 0.f;
     int slw[NE];   // element lane + 64 j of a row: byte slot in bits 16.., index within the slot in bits 0..15
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-        const int e = lane + 64 * j, sl = MODE == MOT_MIX_SUM ? e / A.Db : 0;
-        slw[j] = (sl << 16) | (e - sl * A.Db);
+        const int eb = max(lane + 64 * j - A.byte_lo, 0), sl = BYTES ? eb / A.Db : 0;
+        slw[j] = (sl << 16) | (eb - sl * A.Db);
     }
     // fixed-point scale of the privatised byte-table sums (see embed_mix_bwd_kernel): chosen per workgroup from the
     // upstream gradient rows of the waves' first positions, v * 2^fx_k with the sample's max |g * scale_byte| at 2^24.
     // Terms that would land outside [2^12, 2^40) -- and rows without a slot -- take the exact global atomic.
     int fx_k = 0;
     float fx_hi = 0.f, fx_lo = 0.f;
-    bool fx_known = MODE != MOT_MIX_SUM;
+    bool fx_known = !BYTES;
     auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
     auto add_byte = [&](int id, int wi, float v) {
         const int sl = byte_slot(id);
@@ -389,9 +401,10 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     int cur = -1;
     auto flush = [&]() {
         if (cur < 0) return;
-        float *drow = A.d_tok + (int64_t)cur * D + lane;
+        float *drow = A.d_tok + (int64_t)cur * A.Dt + lane - A.tok_lo;
 #pragma unroll
-        for (int j = 0; j < NE; ++j) atomicAdd(drow + 64 * j, acc[j]);
+        for (int j = 0; j < NE; ++j)
+            if (tmask >> j & 1) atomicAdd(drow + 64 * j, acc[j]);
     };
     auto load_id = [&](const int64_t *ids, int64_t n) {   // lanes < bpt: the token's byte ids, clamped once
         int64_t v = 0;
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
         }
         uint32_t key_nx = skey[s_begin];
         int ida_nx = 0, idb_nx = 0;
-        if (MODE == MOT_MIX_SUM && key_nx != 0xffffffffu) {
+        if (BYTES && key_nx != 0xffffffffu) {
             ida_nx = load_id(A.ids_a, base + (key_nx & 2047));
             if (dual) idb_nx = load_id(A.ids_b, base + (key_nx & 2047));
         }
@@ -466,8 +479,8 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
             }
             float an[NE], bn[NE], dy[NE];
             int idj[NE];
-            const int64_t trow = (int64_t)tok * D + lane, grow = n * D + lane;
-            if (A.in_bf16) {
+            const int64_t trow = (int64_t)tok * A.Dt + lane - A.tok_lo, grow = n * D + lane;
+            if (!SPLIT && A.in_bf16) {
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     an[j] = (float)((const __bf16 *)A.tok_table)[trow + 64 * j];
@@ -476,13 +489,15 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
             } else {
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
-                    an[j] = A.tok_table[trow + 64 * j];
+                    an[j] = (tmask >> j & 1) ? A.tok_table[trow + 64 * j] : 0.f;
                     dy[j] = A.grad_out[grow + 64 * j];
                 }
             }
-            if (MODE == MOT_MIX_SUM) {
+            if (BYTES) {
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
+                    bn[j] = 0.f; idj[j] = 0;
+                    if (!(bmask >> j & 1)) continue;
                     const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
                     idj[j] = __shfl(ida, sl, 64);
                     const int64_t o1 = (int64_t)idj[j] * A.Db + wi;
@@ -499,8 +514,24 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                 }
             }
             float rnb = 1.f;   // lanes < bpt: 1/rms of the slot's byte row
-            if (MODE == MOT_MIX_SUM && A.norm_byte) {
-                rnb = A.byte_rnorm[ida];
+            if (BYTES && A.norm_byte) {
+                if (pair_norm) {   // the rms factor belongs to the (token, slot) pair: per-slot sum of squares in fixed point
+                    float pmax = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) pmax = fmaxf(pmax, bn[j] * bn[j]);
+                    pmax = wave_max(pmax);
+                    const int kk = (pmax > 0.f && pmax < INFINITY) ? 40 - ilogbf(pmax) : 0;
+                    seg_q[lane] = 0ull;
+                    __threadfence_block();
+#pragma unroll
+                    for (int j = 0; j < NE; ++j)
+                        if (bmask >> j & 1) atomicAdd(seg_q + (slw[j] >> 16), to_fixed(bn[j] * bn[j], kk));
+                    __threadfence_block();
+                    rnb = rms_scale((float)ldexp((double)(long long)seg_q[lane], -kk), A.Db, A.eps);
+                    __threadfence_block();
+                } else {
+                    rnb = A.byte_rnorm[ida];
+                }
 #pragma unroll
                 for (int j = 0; j < NE; ++j) bn[j] *= __shfl(rnb, slw[j] >> 16, 64);
             }
@@ -510,7 +541,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                 float ss = 0.f;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
-                ra = rms_scale(wave_sum(ss), D, A.eps);
+                ra = rms_scale(wave_sum(ss), A.Dt, A.eps);
 #pragma unroll
                 for (int j = 0; j < NE; ++j) an[j] *= ra;
             }
@@ -537,7 +568,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                 for (int j = 0; j < NE; ++j) dot += dy[j] * an[j];
                 ds_t += dot;
                 float mt = 0.f;
-                if (A.norm_tok) mt = wave_sum(dot * s_tok) / (float)D;
+                if (A.norm_tok) mt = wave_sum(dot * s_tok) / (float)A.Dt;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const float da = dy[j] * s_tok;
@@ -545,7 +576,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                 }
             }
             // ---- byte side
-            if (MODE == MOT_MIX_SUM) {
+            if (BYTES) {
                 float dot = 0.f;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) { dot += dy[j] * bn[j]; dy[j] *= s_byte; }
@@ -562,7 +593,8 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     seg_q[lane] = 0ull;
                     __threadfence_block();
 #pragma unroll
-                    for (int j = 0; j < NE; ++j) atomicAdd(seg_q + (slw[j] >> 16), to_fixed(dy[j] * bn[j], kk));
+                    for (int j = 0; j < NE; ++j)
+                        if (bmask >> j & 1) atomicAdd(seg_q + (slw[j] >> 16), to_fixed(dy[j] * bn[j], kk));
                     __threadfence_block();
                     float sg = (float)ldexp((double)(long long)seg_q[lane], -kk) / (float)A.Db;
                     if (!(pmax < INFINITY)) sg = NAN;   // non-finite gradients stay non-finite
@@ -575,6 +607,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                 }
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
+                    if (!(bmask >> j & 1)) continue;
                     const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
                     add_byte(idj[j], wi, dy[j]);
                     if (dual) add_byte(__shfl(idb, sl, 64), wi, dy[j]);
@@ -584,8 +617,8 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     }
     flush();
     if (A.d_scale_tok) { ds_t = wave_sum(ds_t); if (lane == 0) atomicAdd(A.d_scale_tok, ds_t); }
-    if (MODE == MOT_MIX_SUM && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
-    if (MODE == MOT_MIX_SUM) {
+    if (BYTES && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
+    if (BYTES) {
         __syncthreads();
         for (int i = tid; i < nbyte; i += kBwdThreads) {
             const long long q = (long long)dbyte_q[i];
@@ -664,8 +697,13 @@ static int launch_bwd_full(const BwdArgs &A, size_t lds, hipStream_t stream) {
 // rows that are "full" (see embed_mix_bwd_full_kernel): SUM / NOOP, D a multiple of 64 with a built NE
 template <int MODE>
 static bool full_layout(const BwdArgs &A) {
-    if (MODE == MOT_MIX_CONCAT_LINEAR || (A.D & 63) || A.Dt != A.D || A.tok_lo != 0) return false;
-    if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D || A.Db > 0xffff)) return false;
+    if (A.D & 63) return false;
+    if (MODE == MOT_MIX_CONCAT_LINEAR) {   // split row: every 64-element chunk wholly token part or wholly byte part
+        if ((A.Dt & 63) || (A.tok_lo & 63) || (A.byte_lo & 63) || (A.nbk & 63) || A.Dt + A.nbk != A.D || A.Db > 0xffff || A.in_bf16) return false;
+    } else {
+        if (A.Dt != A.D || A.tok_lo != 0) return false;
+        if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D || A.Db > 0xffff)) return false;
+    }
     if (A.abl || A.tok_rows > (1 << 20)) return false;   // (token << 11 | index) must stay below the 0xffffffff sentinel
     const int ne = A.D / 64;
     return ne == 1 || ne == 2 || ne == 4 || ne == 8 || ne == 12 || ne == 16 || ne == 24 || ne == 32;
@@ -712,8 +750,7 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
 #ifdef MOT_DEV_ABLATION
     if (getenv("MOT_BWD_ABL")) A.abl = atoi(getenv("MOT_BWD_ABL"));
 #endif
-    bool full = false;
-    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) full = full_layout<MODE>(A);
+    const bool full = full_layout<MODE>(A);
     size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
     if (full) {
         // the lean kernel groups positions by token inside LDS, chunk by chunk: >= 256 chunks when there are enough tokens
@@ -751,9 +788,7 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
             A.byte_rnorm = rnorm_ws;
         }
     }
-    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
-        if (full) return dispatch_ne_full<MODE>(A, lds, stream);
-    }
+    if (full) return dispatch_ne_full<MODE>(A, lds, stream);
     return dispatch_ne<MODE>(A, lds, stream);
 }
 
