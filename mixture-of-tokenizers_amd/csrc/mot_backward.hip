@@ -400,7 +400,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     float acc[NE];
     int cur = -1;
     auto flush = [&]() {
-        if (cur < 0) return;
+        if (cur < 0 || (A.abl & 2)) return;
         float *drow = A.d_tok + (int64_t)cur * A.Dt + lane - A.tok_lo;
 #pragma unroll
         for (int j = 0; j < NE; ++j)
@@ -489,8 +489,8 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
             } else {
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
-                    an[j] = (tmask >> j & 1) ? A.tok_table[trow + 64 * j] : 0.f;
-                    dy[j] = A.grad_out[grow + 64 * j];
+                    an[j] = (tmask >> j & 1) ? A.tok_table[(A.abl & 8) ? lane + 64 * j : trow + 64 * j] : 0.f;   // abl 8: one hot row
+                    dy[j] = A.grad_out[(A.abl & 8) ? lane + 64 * j : grow + 64 * j];
                 }
             }
             if (BYTES) {
@@ -607,7 +607,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                 }
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
-                    if (!(bmask >> j & 1)) continue;
+                    if (!(bmask >> j & 1) || (A.abl & 1)) continue;
                     const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
                     add_byte(idj[j], wi, dy[j]);
                     if (dual) add_byte(__shfl(idb, sl, 64), wi, dy[j]);
@@ -704,7 +704,8 @@ static bool full_layout(const BwdArgs &A) {
         if (A.Dt != A.D || A.tok_lo != 0) return false;
         if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D || A.Db > 0xffff)) return false;
     }
-    if (A.abl || A.tok_rows > (1 << 20)) return false;   // (token << 11 | index) must stay below the 0xffffffff sentinel
+    if ((A.abl & 4) || A.tok_rows > (1 << 20)) return false;   // abl 4: dev switch back to the general kernel
+   // (token << 11 | index) must stay below the 0xffffffff sentinel
     const int ne = A.D / 64;
     return ne == 1 || ne == 2 || ne == 4 || ne == 8 || ne == 12 || ne == 16 || ne == 24 || ne == 32;
 }
