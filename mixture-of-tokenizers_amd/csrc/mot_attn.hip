@@ -88,19 +88,40 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
         pos = r0 / A.H;
         hk = (int)(r0 - pos * A.H);
     }
-    for (int c = 0; c < A.bpt; ++c) {
-        int64_t row = pos;
+    // software pipeline: key c+1's row, rotary row and value are requested before key c's score chain (exp, max) runs;
+    // the rotary row is re-read only when the kv position changes (as_viewed walks H heads per position)
+    auto row_of = [&](int64_t p) {
+        int64_t row = p;
         if (A.ids) {
-            row = A.ids[pos];
+            row = A.ids[p];
             if ((uint64_t)row >= (uint64_t)A.rows) {
                 if (A.status && lane == 0) atomicOr(A.status, kStatusByteOor);
                 row = 0;
             }
         }
+        return row;
+    };
+    float k0n, k1n, v0n, v1n, ckn, skn;
+    {
+        const int64_t row = row_of(pos);
         const float *kp = A.kt + row * HD + hk * kHd, *vp = A.vt + row * HD + hk * kHd;
-        const float k0 = kp[lane], k1 = kp[64 + lane];
-        const float ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
-        const float v0 = vp[lane], v1 = vp[64 + lane];
+        k0n = kp[lane]; k1n = kp[64 + lane]; v0n = vp[lane]; v1n = vp[64 + lane];
+        ckn = A.cos_k[pos * 64 + lane]; skn = A.sin_k[pos * 64 + lane];
+    }
+    for (int c = 0; c < A.bpt; ++c) {
+        const float k0 = k0n, k1 = k1n, v0 = v0n, v1 = v1n, ck = ckn, sk = skn;
+        if (c + 1 < A.bpt) {
+            const int64_t pos_prev = pos;
+            if (A.layout == 0) {
+                if (++hk == A.H) { hk = 0; ++pos; }
+            } else {
+                ++pos;
+            }
+            const int64_t row = row_of(pos);
+            const float *kp = A.kt + row * HD + hk * kHd, *vp = A.vt + row * HD + hk * kHd;
+            k0n = kp[lane]; k1n = kp[64 + lane]; v0n = vp[lane]; v1n = vp[64 + lane];
+            if (pos != pos_prev) { ckn = A.cos_k[pos * 64 + lane]; skn = A.sin_k[pos * 64 + lane]; }
+        }
         const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
         const float s = wave_sum(q0 * ka + q1 * kb) / sqrt_hd;   // line 286
         const float mn = fmaxf(m, s);
@@ -109,11 +130,6 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
         y0 = y0 * scale + p * v0;
         y1 = y1 * scale + p * v1;
         m = mn;
-        if (A.layout == 0) {
-            if (++hk == A.H) { hk = 0; ++pos; }
-        } else {
-            ++pos;
-        }
     }
     float *yp = A.y + t * HD + h * kHd;
     yp[lane] = y0 / l;
