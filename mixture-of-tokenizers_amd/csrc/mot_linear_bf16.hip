@@ -285,6 +285,13 @@ __global__ __launch_bounds__(kThreads * RG, 1) void embed_mix_linear_bf16_kernel
         }
     }
     if (A.norm_out) {
+        // y is a bf16 tensor in the reference (CastedLinear output, train_gpt.py:185-186) before norm() upcasts it (172-173)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (float)(__bf16)acc[mt][nt][r];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

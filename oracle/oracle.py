@@ -56,7 +56,8 @@ def set_eps(eps: float) -> None:
 
 
 def set_round_segments_bf16(on: bool) -> None:
-    """Round the (normalised, scaled) concat operand to bf16 before the contraction: the bf16 F.linear path."""
+    """bf16 F.linear emulation: round the (normalised, scaled) concat operand to bf16 before the contraction and the
+    contraction's result to bf16 after it (both are bf16 tensors in the reference's eager bf16 run)."""
     lib().oracle_set_round_segments_bf16(C.c_int(int(on)))
 
 
