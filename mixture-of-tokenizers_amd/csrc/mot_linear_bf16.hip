@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads * RG, 1) void embed_mix_linear_bf16_kernel
     constexpr int AP = (kTM * kPPR + NTHR - 1) / NTHR;
     // three register sets: the loads of K steps s+1, s+2, s+3 are in flight while step s is multiplied (one step of
     // 12 MFMAs is ~0.2 us, an L2 round trip under load 1-2 us)
-    constexpr int kSets = 3;
+    constexpr int kSets = NT >= 8 ? 2 : 3;   // the widest variant has no registers for a third set
     bf16x8 wreg[kSets][WP], areg[kSets][AP], areg2[kSets][AP];
     float afac[kSets][AP];
     bool atok[kSets][AP];
@@ -260,17 +260,25 @@ __global__ __launch_bounds__(kThreads * RG, 1) void embed_mix_linear_bf16_kernel
     };
     load_stage(0, S0{});
     load_stage(min(1, nsteps - 1), S1{});
-    load_stage(min(2, nsteps - 1), S2{});
+    if constexpr (kSets == 3) load_stage(min(2, nsteps - 1), S2{});
     store_stage(0, S0{});
     __syncthreads();
     int s = 0;
-    for (; s + 3 <= nsteps; s += 3) {
-        step(s, S0{}, S1{});
-        step(s + 1, S1{}, S2{});
-        step(s + 2, S2{}, S0{});
+    if constexpr (kSets == 3) {
+        for (; s + 3 <= nsteps; s += 3) {
+            step(s, S0{}, S1{});
+            step(s + 1, S1{}, S2{});
+            step(s + 2, S2{}, S0{});
+        }
+        if (s < nsteps) step(s, S0{}, S1{});
+        if (s + 1 < nsteps) step(s + 1, S1{}, S2{});
+    } else {
+        for (; s + 2 <= nsteps; s += 2) {
+            step(s, S0{}, S1{});
+            step(s + 1, S1{}, S0{});
+        }
+        if (s < nsteps) step(s, S0{}, S1{});
     }
-    if (s < nsteps) step(s, S0{}, S1{});
-    if (s + 1 < nsteps) step(s + 1, S1{}, S2{});
 
     // ---- epilogue.  C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     if (P.bias) {
@@ -286,19 +294,14 @@ __global__ __launch_bounds__(kThreads * RG, 1) void embed_mix_linear_bf16_kernel
     }
     if (A.norm_out) {
         // y is a bf16 tensor in the reference (CastedLinear output, train_gpt.py:185-186) before norm() upcasts it (172-173)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = (float)(__bf16)acc[mt][nt][r];
+        // (rounded where it is used, twice, rather than in a pass of its own: that pass made the widest variant spill)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float ss = 0.f;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) ss += acc[mt][nt][r] * acc[mt][nt][r];  // padded columns hold 0
+                for (int nt = 0; nt < NT; ++nt) { const float yv = (float)(__bf16)acc[mt][nt][r]; ss += yv * yv; }  // padded columns hold 0
 #pragma unroll
                 for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
                 if (li == 0) rowss[cg * kTM + m0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = ss;
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(kThreads * RG, 1) void embed_mix_linear_bf16_kernel
                 const float tot = ((rowss[m] + rowss[kTM + m]) + rowss[2 * kTM + m]) + rowss[3 * kTM + m];
                 const float rs = rms_scale(tot, P.Dm, A.eps);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] *= rs;
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt][r] = (float)(__bf16)acc[mt][nt][r] * rs;
                 if (P.row_rnorm && cg == 0 && li == 0 && m < ntok) P.row_rnorm[row * A.T + t0 + m] = rs;
             }
     }
