@@ -237,3 +237,35 @@ def test_grad_bucket_accumulates_in_place(mot):
     (fe(dev(toks)) * dev(g)).sum().backward()
     for a, p in zip(acc, bucket.params):
         assert rel(host(a), host(p.grad)) < TOL
+
+
+def test_sum_backward_many_chunks(mot):
+    """More positions than 256 workgroups x 2048: the lean kernel's workgroups loop over several LDS-sorted chunks, the
+    last one partial (N = 3 x 200 001 is not a multiple of anything convenient), with a tiny vocabulary so that every
+    chunk is one long run per token."""
+    D, Db, bpt, Vt, B, T = 64, 8, 8, 37, 3, 200001
+    rs = np.random.RandomState(9401)
+    toks = rs.randint(0, Vt, (B, T)).astype(np.int32)
+    ids = rs.randint(0, gi.BYTE_VOCAB, (B, T * bpt)).astype(np.int64)
+    Et, Eb = f32(gi.normal_table(9402, Vt, D)), f32(gi.normal_table(9403, gi.BYTE_VOCAB, Db))
+    g = f32(rs.standard_normal((B, T, D)))
+    ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64),
+                            mode="sum", bpt=bpt, dtype=np.float64, norm_out=True)
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(ids), norm_out=True)
+    mot.check_status()
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+    assert rel(host(got["byte_table"]), ref["byte_table"]) < TOL
+
+
+def test_backward_flags_out_of_range_ids(mot):
+    D, Db, bpt, Vt, T = 64, 8, 8, 50, 300
+    toks = torch.randint(0, Vt, (1, T), dtype=torch.int32, device=DEV)
+    ids = torch.randint(0, gi.BYTE_VOCAB, (1, T * bpt), dtype=torch.int64, device=DEV)
+    toks[0, 7] = Vt + 5
+    ids[0, 11] = 9999
+    Et, Eb = torch.randn(Vt, D, device=DEV), torch.randn(gi.BYTE_VOCAB, Db, device=DEV)
+    g = torch.randn(1, T, D, device=DEV)
+    got = mot.functional.embed_mix_backward(g, toks, Et, Eb, mode="sum", bpt=bpt, ids_a=ids)
+    assert bool(torch.isfinite(got["tok_table"]).all())
+    with pytest.raises(IndexError):
+        mot.check_status()
