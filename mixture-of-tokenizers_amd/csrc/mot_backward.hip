@@ -995,16 +995,73 @@ static int launch_widen(const void *src, size_t n, float *dst, hipStream_t strea
     return check_launch("widen_kernel");
 }
 
+// du = dy . W of the bf16 backward on the bf16 MFMA (what autograd does for bf16 parameters): dy rounded to bf16,
+// W^T as the [K, Dm] "weight" of the forward bf16 kernel in dense-row mode, du widened back for the scatter stage.
+// Scratch behind the fp32 layouts, in bytes: [dy16: N*Dm*2][wt16: K*Dm*2][du16: N*K*2][byte0: 16][kernel workspace].
+struct Du16Layout { size_t dy16, wt16, du16, byte0, lin, lin_bytes, total; };
+static void du16_desc(MotEmbedMixDesc &g, const MotEmbedMixDesc &d, int64_t N, int K) {
+    memset(&g, 0, sizeof(g));
+    g.struct_size = sizeof(g); g.dtype = MOT_BF16;
+    g.n_rows = 1; g.tokens_per_row = N; g.bpt = 0; g.mode = MOT_MIX_CONCAT_LINEAR;
+    g.id_source = MOT_IDS_GIVEN;
+    g.tok_rows = N; g.tok_dim = d.model_dim; g.byte_rows = 1; g.byte_dim = 8;
+    g.model_dim = K; g.status = d.status;
+}
+static Du16Layout du16_layout(const MotEmbedMixDesc &d) {
+    Du16Layout U;
+    const size_t N = (size_t)(d.n_rows * d.tokens_per_row), K = (size_t)d.tok_dim + (size_t)d.bpt * d.byte_dim, Dm = (size_t)d.model_dim;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
+    U.dy16 = take(N * Dm * 2); U.wt16 = take(K * Dm * 2); U.du16 = take(N * K * 2); U.byte0 = take(16);
+    MotEmbedMixDesc g;
+    du16_desc(g, d, (int64_t)N, (int)K);
+    U.lin_bytes = embed_mix_linear_bf16_workspace_bytes(g);
+    U.lin = take(U.lin_bytes);
+    U.total = o;
+    return U;
+}
+static bool du16_usable(const MotEmbedMixDesc &d) {
+    const int K = d.tok_dim + d.bpt * d.byte_dim;
+    return d.dtype == MOT_BF16 && (d.model_dim & 7) == 0 && (K & 7) == 0 && K <= 1024 && !getenv("MOT_NO_DU16");
+}
+
+__global__ __launch_bounds__(kThreads) void narrow_kernel(const float *__restrict__ src, int64_t n, __bf16 *__restrict__ dst) {
+    for (int64_t i = ((int64_t)blockIdx.x * kThreads + threadIdx.x) * 8; i < n; i += (int64_t)gridDim.x * kThreads * 8) {
+        if (i + 8 <= n) {   // both buffers are 256-byte aligned workspace regions
+            float8v v;
+            const float4v a = *(const float4v *)(src + i), b = *(const float4v *)(src + i + 4);
+            v = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+            Elem<__bf16>::storev_nt(dst + i, v);
+        } else {
+            for (int64_t j = i; j < n; ++j) dst[j] = (__bf16)src[j];
+        }
+    }
+}
+
+// dst[c][r] = src[r][c]   (rows x cols -> cols x rows), bf16, 32 x 32 tiles through LDS
+__global__ __launch_bounds__(kThreads) void transpose_bf16_kernel(const __bf16 *__restrict__ src, int rows, int cols, __bf16 *__restrict__ dst) {
+    __shared__ __bf16 tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(int64_t)(r0 + r) * cols + c0 + tx] : (__bf16)0.f;
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < cols && r0 + tx < rows) dst[(int64_t)(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
 static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
     if (d.mode == MOT_MIX_CONCAT_LINEAR) {
         // the du GEMM runs through launch_embed_mix_linear_ex with its own (small) scratch after ours
-        return (lin_bwd_layout(d).total + (d.dtype == MOT_BF16 ? up_layout(d).total : 0)) * 4 + 64;
+        return (lin_bwd_layout(d).total + (d.dtype == MOT_BF16 ? up_layout(d).total : 0)) * 4 + 256 + (du16_usable(d) ? du16_layout(d).total : 0);
     }
     return (bwd_rnorm_floats(d) + scatter_ws_ints(d)) * 4;
 }
 
-static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream) {
+// `w16` / `ws16` (optional): the bf16 weight and the Du16Layout scratch -- then du runs on the bf16 MFMA
+static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream, const void *w16 = nullptr,
+                                       char *ws16 = nullptr) {
     if (d.id_source != MOT_IDS_GIVEN) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
     if (!gr.d_weight) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: d_weight missing");
     if (d.norm_out && (!d.out || !d.out_row_rnorm)) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: needs the forward's out and out_row_rnorm");
@@ -1033,6 +1090,12 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         d32.eps = d.eps > 0.f ? d.eps : kBf16Eps;   // the forward normalised with the bf16 epsilon
         d32.workspace = up + U.total; d32.workspace_bytes = d.workspace_bytes - U.total * 4;
         g32.grad_out = up + U.g;
+        if (du16_usable(d)) {
+            const size_t off = ((U.total + L.total) * 4 + 255) & ~(size_t)255;
+            if (d.workspace_bytes < off + du16_layout(d).total)
+                return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", off + du16_layout(d).total, d.workspace_bytes);
+            return launch_embed_mix_bwd_linear(d32, g32, stream, d.weight, (char *)d.workspace + off);
+        }
         return launch_embed_mix_bwd_linear(d32, g32, stream);
     }
     if (!d.workspace || d.workspace_bytes < L.total * 4)
@@ -1064,8 +1127,28 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     float *dW = (float *)gr.d_weight;
     if ((rc = launch_gemm_tn(dyp, Dm, Dm, utok, Dt, Dt, N, dW + tok_lo, K, stream))) return rc;
     if ((rc = launch_gemm_tn(dyp, Dm, Dm, ubyte, nbk, nbk, N, dW + byte_lo, K, stream))) return rc;
-    // 3. du = dy . W through the forward MFMA kernel: "token rows" = dy (ids 0..N-1), no byte part, weight operand = W itself
     hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(kThreads), 0, stream, iota, N);
+    if (w16) {
+        // 3'. du on the bf16 MFMA: bf16(dy) rows x W^T, through the forward bf16 kernel in dense-row mode, widened for step 4
+        const Du16Layout U = du16_layout(d);
+        __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16), *wt16 = (__bf16 *)(ws16 + U.wt16), *du16 = (__bf16 *)(ws16 + U.du16);
+        size_t nb = ((size_t)N * Dm / 8 + kThreads) / kThreads;
+        if (nb > 4096) nb = 4096;
+        hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dyp, (int64_t)N * Dm, dy16);
+        hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream,
+                           (const __bf16 *)w16, Dm, K, wt16);
+        hipError_t e16 = hipMemsetAsync(ws16 + U.byte0, 0, 16, stream);
+        if (e16 != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e16));
+        if ((rc = check_launch("iota/narrow/transpose"))) return rc;
+        MotEmbedMixDesc g16;
+        du16_desc(g16, d, N, K);
+        g16.tokens = iota; g16.ids_a = (const int64_t *)iota;  // never read with bpt == 0
+        g16.tok_table = dy16; g16.byte_table = ws16 + U.byte0; g16.weight = wt16; g16.out = du16;
+        g16.workspace = ws16 + U.lin; g16.workspace_bytes = U.lin_bytes;
+        if ((rc = launch_embed_mix_linear_bf16(g16, stream))) return rc;
+        if ((rc = launch_widen(du16, (size_t)N * K, du, stream))) return rc;
+    } else {
+    // 3. du = dy . W through the forward MFMA kernel: "token rows" = dy (ids 0..N-1), no byte part, weight operand = W itself
     hipLaunchKernelGGL(pad_copy_kernel, dim3(512), dim3(kThreads), 0, stream, (const float *)d.weight, Dm, K, wk, L.Dmp, L.Kp);
     hipError_t e = hipMemsetAsync(byte0, 0, 16, stream);
     if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
@@ -1078,6 +1161,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     g2.tok_table = dyp; g2.tok_rows = N; g2.tok_dim = Dm; g2.byte_table = byte0; g2.byte_rows = 1; g2.byte_dim = 4;
     g2.model_dim = K; g2.out = du; g2.status = d.status;
     if ((rc = launch_embed_mix_linear_ex(g2, wk, L.Kp, stream))) return rc;
+    }
     // 4. table gradients from du (its row layout is the concat layout)
     BwdArgs A;
     fill_bwd_args(A, d, gr);

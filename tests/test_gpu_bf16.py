@@ -165,7 +165,9 @@ def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
 # The kernels read bf16 operands, accumulate in fp32 and hand fp32 sums to the autograd node, which rounds
 # once to the parameter dtype.  Oracle: float64 backward on the same bf16-valued operands with eps = 2^-7.
 #   * fp32 sums (embed_mix_backward called directly), SUM/NOOP: same bar as the fp32 backward, 2e-5 of max|ref|;
-#   * CONCAT_LINEAR: the saved forward output x is bf16 (2^-9 relative per element) and enters dy, so 2e-3;
+#   * CONCAT_LINEAR: the saved forward output x is bf16 (2^-9 relative per element) and enters dy, and du = dy.W runs on the
+#     bf16 MFMA with bf16 dy and a bf16 result, as autograd's own bf16 matmul backward does (another 2^-9 per element of
+#     du, partly averaged out by the scatter sums), so 4e-3 of max|ref|;
 #   * .grad on bf16 parameters: additionally one bf16 rounding of each element (2^-8 relative).
 # ------------------------------------------------------------------------------------------------
 def relmax(got, ref):
@@ -242,7 +244,7 @@ def test_bf16_concat_backward_through_autograd(mot, Dt, Db, bpt, Dm, Vt, B, T, k
         assert p.grad.dtype == torch.bfloat16
         r = np.asarray(ref[name], dtype=np.float64)
         err = np.abs(host(p.grad.float()).astype(np.float64) - r)
-        assert (err <= 2.0 ** -8 * np.abs(r) + 2e-3 * np.abs(r).max()).all(), name
+        assert (err <= 2.0 ** -8 * np.abs(r) + 4e-3 * np.abs(r).max()).all(), (name, float((err / np.abs(r).max()).max()))
 
 
 def test_bf16_training_step_through_modules(mot):
