@@ -57,6 +57,16 @@ def write_data_shard(file: Path, tokens: np.ndarray, dtype=np.uint16) -> None:
         f.write(np.asarray(tokens).astype(dtype).tobytes())
 
 
+def save_file(path: str, data) -> None:
+    """data_creation.py:405-418: a tensor (e.g. the (B, T, 1 + 4*bpt) batch of create_batch) as an int32 shard."""
+    write_data_shard(Path(path), np.asarray(data.cpu() if isinstance(data, Tensor) else data).reshape(-1), dtype=np.int32)
+
+
+def load_file(path: str) -> Tensor:
+    """data_creation.py:421-459: the flat int32 payload of such a file (the caller views it (B, T, 1 + 4*bpt))."""
+    return _load_data_shard(Path(path), dtype=torch.int32)
+
+
 def rank_slice(data: Tensor, pos: int, batch_size: int, seq_len: int, rank: int, world_size: int) -> Tensor:
     """train_gpt.py:795-797, 804: this rank's (batch_size/world_size, seq_len+1) rows."""
     assert batch_size % world_size == 0

@@ -37,6 +37,18 @@ def test_shard_roundtrip_and_bad_header(tmp_path):
     assert out.dtype == torch.int32 and out.numel() == 5000
 
 
+def test_batch_file_roundtrip(tmp_path):
+    """save_file / load_file (data_creation.py:405-459): the packed (B, T, 1 + 4*bpt) batch as an int32 shard, and the
+    reference's verify_data check (462-470) on it."""
+    from mixture_of_tokenizers_amd import loader
+    B, T, bpt = 2, 5, 4
+    batch = torch.randint(0, 458, (B, T, 1 + 4 * bpt), dtype=torch.int64)
+    loader.save_file(str(tmp_path / "b.bin"), batch)
+    back = loader.load_file(str(tmp_path / "b.bin"))
+    assert back.dtype == torch.int32 and back.numel() == batch.numel()
+    assert torch.equal(back.view(B, T, 1 + 4 * bpt).to(torch.int64), batch)
+
+
 def test_rank_slice_and_shift_match_reference_fixture():
     from mixture_of_tokenizers_amd import loader
     z = np.load(G / "loader.npz")
