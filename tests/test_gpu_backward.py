@@ -269,3 +269,26 @@ def test_backward_flags_out_of_range_ids(mot):
     assert bool(torch.isfinite(got["tok_table"]).all())
     with pytest.raises(IndexError):
         mot.check_status()
+
+
+@pytest.mark.parametrize("D,Vt,B,T,norm_tok,scaled,seed", [
+    (256, 512, 3, 700, True, False, 9501),     # lean kernel, NOOP (tokens-only embedding, train_gpt.py:342-348)
+    (768, 4096, 2, 300, True, True, 9502),
+    (64, 50, 1, 129, False, False, 9503),
+    (96, 50, 2, 77, True, False, 9504),        # D % 64 != 0: general kernel
+])
+def test_noop_backward_vs_oracle(mot, D, Vt, B, T, norm_tok, scaled, seed):
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et = f32(gi.normal_table(seed + 1, Vt, D))
+    g = f32(np.random.RandomState(seed + 2).standard_normal((B, T, D)))
+    okw, gkw = dict(norm_tok=norm_tok), dict(norm_tok=norm_tok)
+    if scaled:
+        okw.update(scale_tok=1.7)
+        gkw.update(scale_tok=torch.tensor([1.7], device=DEV))
+    ref = orc.embed_mix_bwd(toks, None, None, Et.astype(np.float64), None, g.astype(np.float64), mode="noop", bpt=0, dtype=np.float64, **okw)
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), None, mode="noop", **gkw)
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+    if scaled:
+        assert abs(float(got["scale_tok"]) - ref["scales"][0]) < TOL * max(abs(ref["scales"][0]), 1.0)
+    touched = np.zeros(Vt, bool); touched[toks.reshape(-1)] = True
+    assert not host(got["tok_table"])[~touched].any()          # rows no token touched get exactly zero gradient
