@@ -233,6 +233,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # HIP events on the launch stream
+    # per-launch distribution (median and p10/p90), outside the timed region: 64 individually evented launches
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a, b in evs:
+        a.record(); step(); b.record()
+    torch.cuda.synchronize()
+    lat = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
+    launch_us = {"p10": lat[6], "p50": lat[32], "p90": lat[57]}
     step(counters)                                          # statistics pass, outside the timed region
     torch.cuda.synchronize()
     mot.check_status()
@@ -275,7 +282,7 @@ def main():
                        "global_tokens_per_step": tokens_per_step * world, "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "embed_mix_kernel", "kernel_ms": kernel_ms,
+                         "kernel": "embed_mix_kernel", "kernel_ms": kernel_ms, "launch_us": launch_us,
                          "algorithmic_bytes_per_token": bpt_alg, "tokens_per_launch": tokens_per_step},
             "byte_stats": {"tokens": c[0], "slots": c[1], "pads_before": c[2], "pads_after": c[3],
                            "mean_valid_per_token": (c[1] - c[2]) / max(c[0], 1),
