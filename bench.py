@@ -240,6 +240,20 @@ def main():
     torch.cuda.synchronize()
     lat = sorted(a.elapsed_time(b) * 1e3 for a, b in evs)
     launch_us = {"p10": lat[6], "p50": lat[32], "p90": lat[57]}
+    # what a plain device copy of the same volume reaches on this GPU ("also report against a measured
+    # device-copy bandwidth"): read + write of out-sized buffers, outside the timed region
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(out.numel() * out.element_size() // 4, dtype=torch.float32, device=device).normal_()
+        dst = torch.empty_like(src)
+        dst.copy_(src); torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        c1.record(); torch.cuda.synchronize()
+        copy_gbs = 2 * src.numel() * 4 * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
     step(counters)                                          # statistics pass, outside the timed region
     torch.cuda.synchronize()
     mot.check_status()
@@ -283,6 +297,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "embed_mix_kernel", "kernel_ms": kernel_ms, "launch_us": launch_us,
+                         "device_copy_GBps": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "algorithmic_bytes_per_token": bpt_alg, "tokens_per_launch": tokens_per_step},
             "byte_stats": {"tokens": c[0], "slots": c[1], "pads_before": c[2], "pads_after": c[3],
                            "mean_valid_per_token": (c[1] - c[2]) / max(c[0], 1),
