@@ -536,6 +536,47 @@ def gen_cross_attn(dc, tg):
                 out[f"{name}/{mode}/{dt_name}/x"] = t2n(x)
     np.savez_compressed(OUT / "cross_attn.npz", **out)
     print("cross_attn:", len(out), "arrays")
+    gen_cross_attn_grads(dc, tg)
+
+
+def gen_cross_attn_grads(dc, tg):
+    """loss.backward() through FlexibleEmbedding + ByteMixin(cross_attn) in float64 (train_gpt.py:1319): gradients of
+    every parameter for a fixed upstream gradient.  Table gradients are stored for the rows that were touched only."""
+    out = {}
+    for (name, Vt, D, bpt, T, seed), modes in ((gi.CROSS_CASES[0], ("pulled", "padded_and_pulled")), (gi.CROSS_CASES[1], ("pulled",))):
+        tab = gi.synth_ttb(seed + 1000, Vt, bpt, "left")
+        toks = gi.edge_tokens(seed, 1, T, Vt, eot_p=0.08)
+        padded = dc.tokens_to_bytes(torch.from_numpy(toks), ttb_embedding(tab))
+        pulled = dc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+        Et, Eb = gi.normal_table(seed + 1, Vt, D), gi.normal_table(seed + 2, gi.BYTE_VOCAB, D)
+        q_w, kv_w, p_w = gi.cross_weights(seed + 3, D)
+        g = np.random.RandomState(seed + 9).standard_normal((1, T, D))
+        out[f"{name}/g"] = g.astype(np.float32)
+        for mode in modes:
+            bp = tg["ByteHyperparameters"](bytes_per_token=bpt, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="cross_attn", pull_in=True,
+                                           add_padded_and_pulled=mode == "padded_and_pulled")
+            dims = tg["ModelDims"](model_dim=D, byte_dim=D, token_dim=D)
+            emb, mix = tg["FlexibleEmbedding"](dims, Vt, bp).double(), tg["ByteMixin"](dims, T, bp).double()
+            emb.embed_tokens.weight.data = torch.from_numpy(Et).double()
+            emb.embed_bytes.weight.data = torch.from_numpy(Eb).double()
+            ca = mix.mixin.mixin
+            ca.q_w.data, ca.kv_w.data = torch.from_numpy(q_w).double(), torch.from_numpy(kv_w).double()
+            ca.c_proj.weight.data = torch.from_numpy(p_w).double()
+            ca.lambda_factor.data = torch.tensor(0.7, dtype=torch.float64)
+            xt, xb = emb(tokens=torch.from_numpy(toks), byte_tensor=padded, byte_tensor_pulled=pulled)
+            x = mix(xt, xb)
+            (x * torch.from_numpy(g.astype(np.float32)).double()).sum().backward()
+            for key, p_ in (("d_tok", emb.embed_tokens.weight), ("d_byte", emb.embed_bytes.weight)):
+                gr = t2n(p_.grad)
+                rows = np.flatnonzero(np.abs(gr).sum(1))
+                out[f"{name}/{mode}/{key}_rows"] = rows.astype(np.int32)
+                out[f"{name}/{mode}/{key}_vals"] = gr[rows].astype(np.float32)
+            out[f"{name}/{mode}/d_qw"] = t2n(ca.q_w.grad).astype(np.float32)
+            out[f"{name}/{mode}/d_kvw"] = t2n(ca.kv_w.grad).astype(np.float32)
+            out[f"{name}/{mode}/d_pw"] = t2n(ca.c_proj.weight.grad).astype(np.float32)
+            out[f"{name}/{mode}/d_lambda"] = np.array([float(ca.lambda_factor.grad)])
+    np.savez_compressed(OUT / "cross_attn_grads.npz", **out)
+    print("cross_attn_grads:", len(out), "arrays")
 
 
 def main():

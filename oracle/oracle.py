@@ -283,3 +283,33 @@ def cross_attn(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, l
               _p(cq, C.c_float), _p(sq, C.c_float), _p(ck, C.c_float), _p(sk, C.c_float),
               C.c_int(head_layout), _p(out, real)), "cross_attn")
     return out
+
+
+def cross_attn_bwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor,
+                   cos_q, sin_q, cos_k, sin_k, grad_out, *, bpt, n_heads, head_dim=128, norm_tok=True, norm_byte=True,
+                   head_layout=0, dtype=np.float64):
+    """Gradients of cross_attn w.r.t. (tok_table, byte_table, q_w, kv_w, proj_w, lambda) for upstream gradient
+    grad_out (T, D); float64 arrays (mot_oracle_attn.inc)."""
+    real = C.c_float if dtype == np.float32 else C.c_double
+    fn = lib().oracle_cross_attn_bwd_f32 if dtype == np.float32 else lib().oracle_cross_attn_bwd_f64
+    tok = _c(tokens, np.int32).reshape(-1)
+    T = tok.size
+    tt, bt = _c(tok_table, dtype), _c(byte_table, dtype)
+    D = tt.shape[1]
+    ia = _c(ids_a, np.int64).reshape(-1)
+    ib = None if ids_b is None else _c(ids_b, np.int64).reshape(-1)
+    qw, kvw, pw = _c(q_w, dtype), _c(kv_w, dtype), _c(proj_w, dtype)
+    HD = n_heads * head_dim
+    cq, sq, ck, sk = (_c(a, np.float32) for a in (cos_q, sin_q, cos_k, sin_k))
+    g = _c(grad_out, dtype).reshape(T, D)
+    out = dict(tok_table=np.zeros(tt.shape), byte_table=np.zeros(bt.shape), q_w=np.zeros((HD, D)), kv_w=np.zeros((2, HD, D)),
+               proj_w=np.zeros((D, HD)), lambda_factor=np.zeros(1))
+    _check(fn(_p(tok, C.c_int32), C.c_int64(T), _p(ia, C.c_int64), _p(ib, C.c_int64), C.c_int(bpt),
+              _p(tt, real), C.c_int64(tt.shape[0]), _p(bt, real), C.c_int64(bt.shape[0]), C.c_int(D),
+              C.c_int(int(norm_tok)), C.c_int(int(norm_byte)),
+              _p(qw, real), _p(kvw, real), _p(pw, real), C.c_int(n_heads), C.c_int(head_dim), C.c_double(float(lambda_factor)),
+              _p(cq, C.c_float), _p(sq, C.c_float), _p(ck, C.c_float), _p(sk, C.c_float),
+              C.c_int(head_layout), _p(g, real),
+              _p(out["tok_table"], C.c_double), _p(out["byte_table"], C.c_double), _p(out["q_w"], C.c_double),
+              _p(out["kv_w"], C.c_double), _p(out["proj_w"], C.c_double), _p(out["lambda_factor"], C.c_double)), "cross_attn_bwd")
+    return out

@@ -292,3 +292,29 @@ def test_rotary_buffers_match_the_reference_bit_for_bit():
         np.testing.assert_array_equal(rq.sin.numpy(), z[f"{name}/sin_q"])
         np.testing.assert_array_equal(rk.cos.numpy(), z[f"{name}/cos_k"])
         np.testing.assert_array_equal(rk.sin.numpy(), z[f"{name}/sin_k"])
+
+
+@pytest.mark.parametrize("case,modes", [(gi.CROSS_CASES[0], ("pulled", "padded_and_pulled")), (gi.CROSS_CASES[1], ("pulled",))],
+                         ids=lambda c: c[0] if isinstance(c[0], str) else "")
+def test_cross_attn_backward_oracle_vs_reference_autograd(case, modes):
+    """oracle.cross_attn_bwd == the gradients autograd left on the reference modules (float64 run, train_gpt.py:1319)."""
+    name, Vt, D, bpt, T, seed = case
+    z, zg = np.load(G / "cross_attn.npz"), np.load(G / "cross_attn_grads.npz")
+    Et, Eb = gi.normal_table(seed + 1, Vt, D).astype(np.float64), gi.normal_table(seed + 2, gi.BYTE_VOCAB, D).astype(np.float64)
+    q_w, kv_w, p_w = (a.astype(np.float64) for a in gi.cross_weights(seed + 3, D))
+    rot = [z[f"{name}/{k}"] for k in ("cos_q", "sin_q", "cos_k", "sin_k")]
+    for mode in modes:
+        ids_b = z[f"{name}/padded"] if mode == "padded_and_pulled" else None
+        got = orc.cross_attn_bwd(z[f"{name}/tokens"], z[f"{name}/pulled"], ids_b, Et, Eb, q_w, kv_w, p_w, 0.7, *rot,
+                                 zg[f"{name}/g"].astype(np.float64), bpt=bpt, n_heads=D // 128)
+        def close(a, b, what):
+            assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), (mode, what)   # goldens are stored in float32
+        for key, full in (("d_tok", got["tok_table"]), ("d_byte", got["byte_table"])):
+            rows = zg[f"{name}/{mode}/{key}_rows"]
+            close(full[rows], zg[f"{name}/{mode}/{key}_vals"], key)
+            mask = np.ones(len(full), bool); mask[rows] = False
+            assert np.abs(full[mask]).max(initial=0.0) <= 1e-12 * np.abs(full).max(), key   # rows autograd left at exactly zero
+        close(got["q_w"], zg[f"{name}/{mode}/d_qw"], "q_w")
+        close(got["kv_w"], zg[f"{name}/{mode}/d_kvw"], "kv_w")
+        close(got["proj_w"], zg[f"{name}/{mode}/d_pw"], "proj_w")
+        assert abs(got["lambda_factor"][0] - zg[f"{name}/{mode}/d_lambda"][0]) <= 1e-9 * max(1.0, abs(zg[f"{name}/{mode}/d_lambda"][0]))
