@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 5
+#define MOT_ABI_VERSION 6
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -274,6 +274,26 @@ typedef struct MotCrossAttnDesc {
     void *workspace;          /* mot_cross_attn_workspace_bytes(desc) */
     size_t workspace_bytes;
 } MotCrossAttnDesc;
+
+/*
+ * Backward of mot_cross_attn_fwd (loss.backward() through the modules above, train_gpt.py:1319).  `fwd` is the
+ * forward's descriptor (`out` is ignored); everything is recomputed from the inputs.  Gradients are ACCUMULATED (+=)
+ * in fp32 into the given buffers.  One id tensor only (ids_b must be NULL: MOT_EUNSUPPORTED otherwise).
+ */
+typedef struct MotCrossAttnGrads {
+    uint32_t struct_size;  /* sizeof(MotCrossAttnGrads) */
+    uint32_t reserved;
+    const void *grad_out;  /* [n_tokens, dim] */
+    void *d_tok_table;     /* [tok_rows, dim]  */
+    void *d_byte_table;    /* [byte_rows, dim] */
+    void *d_q_w;           /* [hdim, dim]      */
+    void *d_kv_w;          /* [2, hdim, dim]   */
+    void *d_proj_w;        /* [dim, hdim]      */
+    float *d_lambda;       /* scalar           */
+} MotCrossAttnGrads;
+
+size_t mot_cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc *fwd /* host */);
+int mot_cross_attn_bwd(const MotCrossAttnDesc *fwd /* host */, const MotCrossAttnGrads *grads /* host */, mot_stream_t stream);
 
 size_t mot_cross_attn_desc_size(void);
 size_t mot_cross_attn_workspace_bytes(const MotCrossAttnDesc *desc /* host */);

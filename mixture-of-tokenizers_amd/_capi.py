@@ -23,7 +23,7 @@ MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32, BF16 = 0, 1
 MAX_BPT = 64
-ABI_VERSION = 5
+ABI_VERSION = 6
 HEADS_AS_VIEWED, HEADS_PER_TOKEN = 0, 1
 
 
@@ -39,6 +39,7 @@ EXPORTS = (
     "mot_create_batch", "mot_gather_rows", "mot_embed_mix_desc_size", "mot_embed_mix_workspace_bytes",
     "mot_embed_mix_fwd", "mot_embed_mix_bwd_workspace_bytes", "mot_embed_mix_bwd",
     "mot_cross_attn_desc_size", "mot_cross_attn_workspace_bytes", "mot_cross_attn_fwd",
+    "mot_cross_attn_bwd_workspace_bytes", "mot_cross_attn_bwd",
 )
 
 
@@ -86,6 +87,15 @@ class MotCrossAttnDesc(C.Structure):
     ]
 
 
+class MotCrossAttnGrads(C.Structure):
+    """Mirror of struct MotCrossAttnGrads (include/mot.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("grad_out", C.c_void_p),
+        ("d_tok_table", C.c_void_p), ("d_byte_table", C.c_void_p), ("d_q_w", C.c_void_p), ("d_kv_w", C.c_void_p),
+        ("d_proj_w", C.c_void_p), ("d_lambda", C.c_void_p),
+    ]
+
+
 def _load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise ImportError(
@@ -112,6 +122,10 @@ def _load() -> C.CDLL:
     lib.mot_cross_attn_workspace_bytes.argtypes = [C.POINTER(MotCrossAttnDesc)]
     lib.mot_cross_attn_fwd.argtypes = [C.POINTER(MotCrossAttnDesc), vp]
     lib.mot_cross_attn_fwd.restype = C.c_int
+    lib.mot_cross_attn_bwd_workspace_bytes.restype = C.c_size_t
+    lib.mot_cross_attn_bwd_workspace_bytes.argtypes = [C.POINTER(MotCrossAttnDesc)]
+    lib.mot_cross_attn_bwd.argtypes = [C.POINTER(MotCrossAttnDesc), C.POINTER(MotCrossAttnGrads), vp]
+    lib.mot_cross_attn_bwd.restype = C.c_int
     for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_gather_rows", "mot_embed_mix_fwd",
                  "mot_embed_mix_bwd"):
         getattr(lib, name).restype = C.c_int

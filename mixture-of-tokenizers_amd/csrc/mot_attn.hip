@@ -237,4 +237,350 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     return launch_embed_mix_linear(g, stream);
 }
 
+
+// ==========================================================================================
+// Backward (loss.backward() through ByteMixinCrossAttn + FlexibleEmbedding, train_gpt.py:1319).  One id tensor.
+//   forward recompute   q_pre = W_q xq;  k_pre, v_pre per byte-table row;  k_n = norm_head(k_pre);  y (attention)
+//   dW_p += g^T y                      gemm_tn            dy = g W_p            dense GEMM (prebuilt k-major operand)
+//   cross_attn_bwd_kernel, one wave per (token, head): softmax weights p_c across lanes (lane c holds key c),
+//       dV_l[r] = p_c dy           -> dvl_pos  [T*bpt, HD]   (flat row r = pos*H + head: each written by exactly one query)
+//       dk_n[r] = rope^T(ds_c q_r) -> dkn_pos  [T*bpt, HD]
+//       dq_pre  = norm_head^T(rope^T(sum_c ds_c k_r))        -> dq [T, HD]
+//   per byte-table row: dkn_tab / dvl_tab = sum of the position rows with that id  -- exactly an embedding backward
+//       (launch_embed_mix_bwd, NOOP, "tokens" = byte ids, table rows = the K/V table rows)
+//   kv_table_bwd_kernel: d lambda, d v_pre = lambda dV_l, d k_pre = norm_head^T(dk_n)   -> dkv [R, 2 HD]
+//   dW_kv += dkv^T xkv_tab (gemm_tn, R rows);  dxkv_tab = dkv W_kv (dense GEMM);  byte_rows_bwd_kernel: norm^T, d_byte += (rows ARE table rows)
+//   dW_q += dq^T xq (gemm_tn);  dxq = dq W_q (dense GEMM);  token-table gradient = launch_embed_mix_bwd (NOOP, norm_tok) on dxq
+// ==========================================================================================
+struct AttnBwdArgs {
+    const float *q_pre, *dy;   // [T, HD]
+    const float *kn, *vpre;    // [rows, HD]
+    const float *lambda;
+    const int64_t *ids;
+    int64_t rows, T;
+    int bpt, H, layout;
+    const float *cos_q, *sin_q, *cos_k, *sin_k;
+    float eps;
+    float *dq, *dkn_pos, *dvl_pos;
+};
+
+__global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (w >= A.T * A.H) return;
+    const int64_t t = w / A.H;
+    const int h = (int)(w - t * A.H);
+    const int HD = A.H * kHd;
+    const float lam = *A.lambda;
+    const float inv_sqrt = 1.0f / sqrtf((float)kHd);
+    // q: head norm + RoPE, as in the forward
+    const float *qp = A.q_pre + t * HD + h * kHd;
+    const float qp0 = qp[lane], qp1 = qp[64 + lane];
+    const float rq = rms_scale(wave_sum(qp0 * qp0 + qp1 * qp1), kHd, A.eps);
+    const float qn0 = qp0 * rq, qn1 = qp1 * rq;
+    const float cq = A.cos_q[t * 64 + lane], sq = A.sin_q[t * 64 + lane];
+    const float q0 = qn0 * cq + qn1 * sq, q1 = qn0 * (-sq) + qn1 * cq;
+    const float dy0 = A.dy[t * HD + h * kHd + lane], dy1 = A.dy[t * HD + h * kHd + 64 + lane];
+    int64_t pos0 = t * A.bpt;
+    int hk0 = h;
+    if (A.layout == 0) {
+        const int64_t r0 = ((int64_t)h * A.T + t) * A.bpt;
+        pos0 = r0 / A.H;
+        hk0 = (int)(r0 - pos0 * A.H);
+    }
+    auto advance = [&](int64_t &pos, int &hk) {
+        if (A.layout == 0) { if (++hk == A.H) { hk = 0; ++pos; } } else ++pos;
+    };
+    auto row_of = [&](int64_t p) {
+        int64_t row = A.ids[p];
+        if ((uint64_t)row >= (uint64_t)A.rows) row = 0;   // flagged by the forward
+        return row;
+    };
+    // pass 1: scores; lane c keeps s_c
+    float sc = -FLT_MAX;
+    {
+        int64_t pos = pos0; int hk = hk0;
+        for (int c = 0; c < A.bpt; ++c) {
+            const float *kp = A.kn + row_of(pos) * HD + hk * kHd;
+            const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
+            const float s = wave_sum(q0 * ka + q1 * kb) * inv_sqrt;
+            if (lane == c) sc = s;
+            advance(pos, hk);
+        }
+    }
+    float mx = sc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float p = lane < A.bpt ? expf(sc - mx) : 0.f;
+    p /= wave_sum(p);
+    // pass 2: dp_c = dy . v_c; dV_l rows
+    float dp = 0.f;
+    {
+        int64_t pos = pos0; int hk = hk0;
+        for (int c = 0; c < A.bpt; ++c) {
+            const float *vp = A.vpre + row_of(pos) * HD + hk * kHd;
+            const float v0 = lam * vp[lane], v1 = lam * vp[64 + lane];
+            const float d = wave_sum(dy0 * v0 + dy1 * v1);
+            if (lane == c) dp = d;
+            const float pc = __shfl(p, c, 64);
+            float *o = A.dvl_pos + (pos * A.H + hk) * (int64_t)kHd;
+            o[lane] = pc * dy0;
+            o[64 + lane] = pc * dy1;
+            advance(pos, hk);
+        }
+    }
+    const float dot = wave_sum(p * dp);
+    const float ds = p * (dp - dot) * inv_sqrt;   // lane c
+    // pass 3: dq_r += ds_c k_r;  dk_n = rope^T(ds_c q_r)
+    float dq0 = 0.f, dq1 = 0.f;
+    {
+        int64_t pos = pos0; int hk = hk0;
+        for (int c = 0; c < A.bpt; ++c) {
+            const float *kp = A.kn + row_of(pos) * HD + hk * kHd;
+            const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
+            const float dsc = __shfl(ds, c, 64);
+            dq0 += dsc * ka;
+            dq1 += dsc * kb;
+            const float g0 = dsc * q0, g1 = dsc * q1;             // d k_r
+            float *o = A.dkn_pos + (pos * A.H + hk) * (int64_t)kHd;
+            o[lane] = g0 * ck - g1 * sk;                            // rope^T
+            o[64 + lane] = g0 * sk + g1 * ck;
+            advance(pos, hk);
+        }
+    }
+    // q: rope^T, head-norm^T
+    const float dn0 = dq0 * cq - dq1 * sq, dn1 = dq0 * sq + dq1 * cq;
+    const float m = wave_sum(dn0 * qn0 + dn1 * qn1) / (float)kHd;
+    float *o = A.dq + t * HD + h * kHd;
+    o[lane] = rq * (dn0 - qn0 * m);
+    o[64 + lane] = rq * (dn1 - qn1 * m);
+}
+
+// k_n = norm_head(k_pre), v_l = lambda v_pre    (the forward's kv_finish, out of place)
+__global__ __launch_bounds__(kThreads) void kv_norm_kernel(const float *__restrict__ kpre, const float *__restrict__ vpre, int64_t rows, int H,
+                                                           const float *__restrict__ lambda, float eps, float *__restrict__ kn, float *__restrict__ vl) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (w >= rows * H) return;
+    const float k0 = kpre[w * kHd + lane], k1 = kpre[w * kHd + 64 + lane];
+    const float r = rms_scale(wave_sum(k0 * k0 + k1 * k1), kHd, eps);
+    kn[w * kHd + lane] = k0 * r;
+    kn[w * kHd + 64 + lane] = k1 * r;
+    const float lam = *lambda;
+    vl[w * kHd + lane] = lam * vpre[w * kHd + lane];
+    vl[w * kHd + 64 + lane] = lam * vpre[w * kHd + 64 + lane];
+}
+
+// per (table row, head): d lambda += dV_l . v_pre;  dkv[row][HD + ..] = lambda dV_l;  dkv[row][..] = norm_head^T(dk_n)
+__global__ __launch_bounds__(kThreads) void kv_table_bwd_kernel(const float *__restrict__ dkn, const float *__restrict__ dvl, const float *__restrict__ kpre,
+                                                                const float *__restrict__ vpre, int64_t rows, int H, const float *__restrict__ lambda,
+                                                                float eps, float *__restrict__ dkv, float *__restrict__ d_lambda) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (w >= rows * H) return;
+    const int64_t row = w / H;
+    const int h = (int)(w - row * H);
+    const int HD = H * kHd;
+    const float lam = *lambda;
+    const float dv0 = dvl[w * kHd + lane], dv1 = dvl[w * kHd + 64 + lane];
+    const float dl = wave_sum(dv0 * vpre[w * kHd + lane] + dv1 * vpre[w * kHd + 64 + lane]);
+    if (lane == 0 && d_lambda) atomicAdd(d_lambda, dl);
+    const float k0 = kpre[w * kHd + lane], k1 = kpre[w * kHd + 64 + lane];
+    const float r = rms_scale(wave_sum(k0 * k0 + k1 * k1), kHd, eps);
+    const float kn0 = k0 * r, kn1 = k1 * r, g0 = dkn[w * kHd + lane], g1 = dkn[w * kHd + 64 + lane];
+    const float m = wave_sum(g0 * kn0 + g1 * kn1) / (float)kHd;
+    float *o = dkv + row * 2 * HD + h * kHd;
+    o[lane] = r * (g0 - kn0 * m);
+    o[64 + lane] = r * (g1 - kn1 * m);
+    o[HD + lane] = lam * dv0;
+    o[HD + 64 + lane] = lam * dv1;
+}
+
+// xn[row] = norm?(table[row]) for every table row (the operand the K/V GEMMs saw), one wave per row
+__global__ __launch_bounds__(kThreads) void rows_norm_kernel(const float *__restrict__ table, int64_t rows, int D, int norm, float eps, float *__restrict__ xn) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float ss = 0.f;
+    for (int j = lane; j < D; j += 64) { const float v = table[r * D + j]; ss += v * v; }
+    const float rs = norm ? rms_scale(wave_sum(ss), D, eps) : 1.0f;
+    for (int j = lane; j < D; j += 64) xn[r * D + j] = table[r * D + j] * rs;
+}
+
+// d_byte[row] += norm^T(dxn[row]): the K/V table rows ARE the byte-table rows, so no scatter
+__global__ __launch_bounds__(kThreads) void byte_rows_bwd_kernel(const float *__restrict__ table, const float *__restrict__ dxn, int64_t rows, int D, int norm,
+                                                                 float eps, float *__restrict__ d_table) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    if (!norm) {
+        for (int j = lane; j < D; j += 64) atomicAdd(d_table + r * D + j, dxn[r * D + j]);
+        return;
+    }
+    float ss = 0.f, dot = 0.f;
+    for (int j = lane; j < D; j += 64) { const float v = table[r * D + j]; ss += v * v; dot += dxn[r * D + j] * v; }
+    const float rs = rms_scale(wave_sum(ss), D, eps);
+    const float m = wave_sum(dot) * rs / (float)D;      // mean(dxn * xn), xn = x * rs
+    for (int j = lane; j < D; j += 64) atomicAdd(d_table + r * D + j, rs * (dxn[r * D + j] - table[r * D + j] * rs * m));
+}
+
+__global__ __launch_bounds__(kThreads) void ids_to_i32_kernel(const int64_t *__restrict__ ids, int64_t n, int64_t rows, int32_t *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t v = ids[i];
+        out[i] = (uint64_t)v < (uint64_t)rows ? (int32_t)v : 0;
+    }
+}
+
+static int out_cols_pad(int n) {   // the column padding embed_mix_linear_kernel dispatches on (mot_linear.hip nt_of)
+    int p = (n + 127) / 128 * 128;
+    if (p > 512 && p <= 768) p = 768; else if (p > 768) p = 1024;
+    return p;
+}
+
+// workspace of the backward, in floats
+struct AttnBwdLayout {
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, dkn_pos, dvl_pos, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, iota, byte0, wk, lin, lin_floats, emb, emb_bytes, total;
+};
+static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
+    memset(&e, 0, sizeof(e));
+    e.struct_size = sizeof(e); e.dtype = MOT_F32; e.n_rows = 1; e.tokens_per_row = n; e.mode = MOT_MIX_NOOP;
+    e.tokens = (const int32_t *)tokens; e.tok_table = table; e.tok_rows = rows; e.tok_dim = dim; e.model_dim = dim;
+    e.norm_tok = norm; e.eps = eps; e.status = status;
+}
+static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
+    AttnBwdLayout L;
+    const size_t T = (size_t)d.n_tokens, HD = (size_t)d.n_heads * kHd, D = (size_t)d.dim, R = (size_t)d.byte_rows, P = T * d.bpt;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
+    L.q = take(T * HD); L.y = take(T * HD); L.kpre = take(R * HD); L.vpre = take(R * HD); L.kn = take(R * HD); L.vl = take(R * HD);
+    L.dy = take(T * HD); L.dq = take(T * HD); L.dkn_pos = take(P * HD); L.dvl_pos = take(P * HD);
+    L.dkn_tab = take(R * HD); L.dvl_tab = take(R * HD); L.dkv = take(R * 2 * HD); L.xkv = take(R * D); L.dxkv = take(R * D);
+    L.xq = take(T * D); L.dxq = take(T * D); L.ids32 = take(P); L.iota = take(T > R ? T : R); L.byte0 = take(4);
+    const size_t kc = (2 * HD + 15) / 16 * 16 > (D + 15) / 16 * 16 ? (2 * HD + 15) / 16 * 16 : (D + 15) / 16 * 16;
+    L.wk = take(kc * (size_t)out_cols_pad((int)(HD > D ? HD : D)));
+    MotEmbedMixDesc g;
+    const int64_t max_rows = d.tok_rows > (int64_t)R ? d.tok_rows : (int64_t)R;
+    dense_desc(g, nullptr, nullptr, nullptr, max_rows, 1, (int)D, nullptr, (int)HD, nullptr, nullptr, nullptr, 0);
+    g.norm_tok = 1;
+    L.lin_floats = (embed_mix_linear_workspace_bytes(g) + 3) / 4;
+    L.lin = take(L.lin_floats);
+    MotEmbedMixDesc e;   // the three embedding-backward calls share one scratch: the largest
+    noop_bwd_desc(e, nullptr, (int64_t)T, nullptr, d.tok_rows, (int)D, d.norm_tok, 0.f, nullptr);
+    size_t a = embed_mix_bwd_workspace_bytes(e);
+    noop_bwd_desc(e, nullptr, (int64_t)P, nullptr, (int64_t)R, (int)HD, 0, 0.f, nullptr);
+    size_t b = embed_mix_bwd_workspace_bytes(e);
+    L.emb_bytes = a > b ? a : b;
+    L.emb = take((L.emb_bytes + 3) / 4);
+    L.total = o;
+    return L;
+}
+
+size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d) { return attn_bwd_layout(d).total * 4; }
+
+// out[n][Nout] = rows[n][Kc] . W[Kc][Nout]  (W k-major, unpadded) through the forward MFMA kernel in dense-row mode
+static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *W, int Nout, float *out, float *wk, const int32_t *iota, const float *byte0,
+                             uint32_t *status, hipStream_t stream) {
+    const int kp = (Kc + 15) / 16 * 16, np = out_cols_pad(Nout);
+    int rc;
+    if ((rc = launch_pad_copy(W, Kc, Nout, wk, kp, np, stream))) return rc;
+    MotEmbedMixDesc g;
+    dense_desc(g, iota, byte0, rows, n, n, Kc, nullptr, Nout, out, status, nullptr, 0);
+    return launch_embed_mix_linear_ex(g, wk, np, stream);
+}
+
+int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr, hipStream_t stream) {
+    const int64_t T = d.n_tokens, R = d.byte_rows, P = T * d.bpt;
+    const int H = d.n_heads, HD = H * kHd, D = d.dim;
+    const AttnBwdLayout L = attn_bwd_layout(d);
+    if (!d.workspace || d.workspace_bytes < L.total * 4)
+        return set_error(MOT_EWORKSPACE, "cross_attn_bwd: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
+    float *ws = (float *)d.workspace;
+    float *q = ws + L.q, *y = ws + L.y, *kpre = ws + L.kpre, *vpre = ws + L.vpre, *kn = ws + L.kn, *vl = ws + L.vl, *dy = ws + L.dy, *dq = ws + L.dq;
+    float *dkn_pos = ws + L.dkn_pos, *dvl_pos = ws + L.dvl_pos, *dkn_tab = ws + L.dkn_tab, *dvl_tab = ws + L.dvl_tab, *dkv = ws + L.dkv;
+    float *xkv = ws + L.xkv, *dxkv = ws + L.dxkv, *xq = ws + L.xq, *dxq = ws + L.dxq, *byte0 = ws + L.byte0, *wk = ws + L.wk, *lin = ws + L.lin;
+    int32_t *ids32 = (int32_t *)(ws + L.ids32), *iota = (int32_t *)(ws + L.iota);
+    void *emb_ws = ws + L.emb;
+    const size_t lin_bytes = L.lin_floats * 4;
+    const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    const float *g_out = (const float *)gr.grad_out;
+    int rc;
+    hipLaunchKernelGGL(iota32_kernel, dim3(256), dim3(kThreads), 0, stream, iota, T > R ? T : R);
+    hipLaunchKernelGGL(ids_to_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, d.ids_a, P, R, ids32);
+    if ((rc = check_launch("iota32 / ids_to_i32"))) return rc;
+    hipError_t e = hipMemsetAsync(byte0, 0, 16, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dkn_tab, 0, (size_t)R * HD * 4, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dvl_tab, 0, (size_t)R * HD * 4, stream);
+    if (e != hipSuccess) return set_error(MOT_EHIP, "cross_attn_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+    // ---- forward recompute
+    MotEmbedMixDesc g;
+    dense_desc(g, d.tokens, byte0, d.tok_table, d.tok_rows, T, D, d.q_w, HD, q, d.status, lin, lin_bytes);
+    g.norm_tok = d.norm_tok; g.eps = eps;
+    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+    const float *kv_w = (const float *)d.kv_w;
+    dense_desc(g, iota, byte0, d.byte_table, R, R, D, kv_w, HD, kpre, d.status, lin, lin_bytes);
+    g.norm_tok = d.norm_byte; g.eps = eps;
+    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+    dense_desc(g, iota, byte0, d.byte_table, R, R, D, kv_w + (size_t)HD * D, HD, vpre, d.status, lin, lin_bytes);
+    g.norm_tok = d.norm_byte; g.eps = eps;
+    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+    const int64_t kvw = R * H;
+    hipLaunchKernelGGL(kv_norm_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kpre, vpre, R, H, d.lambda_factor, eps, kn, vl);
+    if ((rc = check_launch("kv_norm_kernel"))) return rc;
+    AttnArgs A;
+    A.q = q; A.y = y; A.kt = kn; A.vt = vl; A.ids = d.ids_a; A.rows = R; A.T = T; A.bpt = d.bpt; A.H = H;
+    A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
+    const int64_t waves = T * H;
+    hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
+    if ((rc = check_launch("cross_attn_kernel"))) return rc;
+    // ---- c_proj:  dW_p += g^T y;  dy = g W_p   (proj_w [D, HD] is the k-major operand of g[T, D] -> dy[T, HD])
+    if (gr.d_proj_w && (rc = launch_gemm_tn(g_out, D, D, y, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
+    if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, wk, iota, byte0, d.status, stream))) return rc;
+    // ---- attention
+    AttnBwdArgs B;
+    B.q_pre = q; B.dy = dy; B.kn = kn; B.vpre = vpre; B.lambda = d.lambda_factor; B.ids = d.ids_a; B.rows = R; B.T = T; B.bpt = d.bpt; B.H = H;
+    B.layout = d.head_layout; B.cos_q = d.cos_q; B.sin_q = d.sin_q; B.cos_k = d.cos_k; B.sin_k = d.sin_k; B.eps = eps;
+    B.dq = dq; B.dkn_pos = dkn_pos; B.dvl_pos = dvl_pos;
+    hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
+    if ((rc = check_launch("cross_attn_bwd_kernel"))) return rc;
+    // ---- per byte-table row: sum the position rows of every id (an embedding backward with "tokens" = byte ids)
+    MotEmbedMixDesc ed;
+    MotEmbedMixGrads eg;
+    memset(&eg, 0, sizeof(eg));
+    eg.struct_size = sizeof(eg);
+    noop_bwd_desc(ed, ids32, P, kn, R, HD, 0, eps, d.status);
+    ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
+    eg.grad_out = dkn_pos; eg.d_tok_table = dkn_tab;
+    if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
+    eg.grad_out = dvl_pos; eg.d_tok_table = dvl_tab;
+    if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
+    hipLaunchKernelGGL(kv_table_bwd_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, dkn_tab, dvl_tab, kpre, vpre, R, H,
+                       d.lambda_factor, eps, dkv, gr.d_lambda);
+    if ((rc = check_launch("kv_table_bwd_kernel"))) return rc;
+    // ---- kv_w and the byte table
+    hipLaunchKernelGGL(rows_norm_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, R, D, d.norm_byte, eps, xkv);
+    if ((rc = check_launch("rows_norm_kernel"))) return rc;
+    if (gr.d_kv_w && (rc = launch_gemm_tn(dkv, 2 * HD, 2 * HD, xkv, D, D, R, (float *)gr.d_kv_w, D, stream))) return rc;
+    if (gr.d_byte_table) {
+        if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, wk, iota, byte0, d.status, stream))) return rc;   // kv_w as [2 HD, D]
+        hipLaunchKernelGGL(byte_rows_bwd_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, dxkv, R, D,
+                           d.norm_byte, eps, (float *)gr.d_byte_table);
+        if ((rc = check_launch("byte_rows_bwd_kernel"))) return rc;
+    }
+    // ---- q_w and the token table
+    if (gr.d_q_w) {
+        if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream))) return rc;
+        if ((rc = launch_gemm_tn(dq, HD, HD, xq, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
+    }
+    if (gr.d_tok_table) {
+        if ((rc = dense_gemm_kmajor(dq, T, HD, (const float *)d.q_w, D, dxq, wk, iota, byte0, d.status, stream))) return rc;   // q_w [HD, D]
+        noop_bwd_desc(ed, d.tokens, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, d.status);
+        ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
+        eg.grad_out = dxq; eg.d_tok_table = gr.d_tok_table;
+        if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
+    }
+    return MOT_OK;
+}
+
 }  // namespace mot

@@ -854,6 +854,11 @@ __global__ __launch_bounds__(kThreads) void pad_copy_kernel(const float *__restr
     }
 }
 
+int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream) {
+    hipLaunchKernelGGL(pad_copy_kernel, dim3(512), dim3(kThreads), 0, stream, src, rows, cols, dst, rows_pad, cols_pad);
+    return check_launch("pad_copy_kernel");
+}
+
 // C[j][k] += sum_n A[n][j] * B[n][k]   (A: n x M, B: n x Nc, C: M x Nc with leading dimension ldc), fp32 MFMA.
 // Workgroup = 128 x 128 output block (4 waves as 2 x 2, each 64 x 64 = 2 x 2 tiles of 32 x 32) over one
 // slice of the rows; 16 rows per step, double-buffered LDS, rows ARE the MFMA k index so both operands are
@@ -931,7 +936,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const float *__restri
             }
 }
 
-static int launch_gemm_tn(const float *A_, int lda, int M, const float *B_, int ldb, int Nc, int64_t n, float *C, int ldc, hipStream_t stream) {
+int launch_gemm_tn(const float *A_, int lda, int M, const float *B_, int ldb, int Nc, int64_t n, float *C, int ldc, hipStream_t stream) {
     if (M <= 0 || Nc <= 0 || n <= 0) return MOT_OK;
     const int gx = (M + 127) / 128, gy = (Nc + 127) / 128;
     int64_t splits = (1024 + gx * gy - 1) / (gx * gy);                  // ~1024 workgroups in total

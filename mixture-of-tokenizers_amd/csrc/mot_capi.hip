@@ -228,4 +228,23 @@ int mot_cross_attn_fwd(const MotCrossAttnDesc *desc, mot_stream_t stream) {
     return launch_cross_attn(*desc, (hipStream_t)stream);
 }
 
+size_t mot_cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc *desc) {
+    if (!desc || desc->struct_size != sizeof(MotCrossAttnDesc) || desc->n_heads < 1 || desc->bpt < 1 || desc->n_tokens < 0) return 0;
+    return cross_attn_bwd_workspace_bytes(*desc);
+}
+
+int mot_cross_attn_bwd(const MotCrossAttnDesc *desc, const MotCrossAttnGrads *grads, mot_stream_t stream) {
+    if (!grads || grads->struct_size != sizeof(MotCrossAttnGrads))
+        return set_error(MOT_EINVAL, "cross_attn_bwd: grads struct missing or struct_size mismatch");
+    if (!desc) return set_error(MOT_EINVAL, "cross_attn_bwd: null descriptor");
+    MotCrossAttnDesc d = *desc;
+    if (!d.out) d.out = (void *)grads->grad_out;   // the forward validator wants a non-null `out`; the backward never writes it
+    int rc = validate_cross_attn(&d);
+    if (rc) return rc;
+    if (d.ids_b) return set_error(MOT_EUNSUPPORTED, "cross_attn_bwd: the two-id-tensor embedding (norm(E[a] + E[b])) is forward-only");
+    if (!grads->grad_out) return set_error(MOT_EINVAL, "cross_attn_bwd: grad_out missing");
+    if (d.n_tokens == 0) return MOT_OK;
+    return launch_cross_attn_bwd(d, *grads, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -34,6 +34,11 @@ size_t embed_mix_linear_bf16_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix_linear_bf16(const MotEmbedMixDesc &d, hipStream_t stream);
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hipStream_t stream);
+// C[j][k] += sum_n A[n][j] * B[n][k]  (A: n x M, B: n x Nc; fp32 MFMA, atomic accumulate)
+int launch_gemm_tn(const float *A, int lda, int M, const float *B, int ldb, int Nc, int64_t n, float *C, int ldc, hipStream_t stream);
+int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream);
+size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d);
+int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &g, hipStream_t stream);
 size_t cross_attn_workspace_bytes(const MotCrossAttnDesc &d);
 int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream);
 

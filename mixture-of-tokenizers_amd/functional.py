@@ -430,23 +430,9 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
     return _embed_mix_fwd(tokens, tok_table, byte_table, scale_tok=scale_tok, scale_byte=scale_byte, **kw)
 
 
-@torch.compiler.disable
-def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor, *,
-               q_w: torch.Tensor, kv_w: torch.Tensor, proj_w: torch.Tensor, lambda_factor: torch.Tensor,
-               cos_q: torch.Tensor, sin_q: torch.Tensor, cos_k: torch.Tensor, sin_k: torch.Tensor,
-               bpt: int, n_heads: int, ids_b: torch.Tensor | None = None, norm_tok: bool = True, norm_byte: bool = True,
-               head_layout: str = "as_viewed", eps: float | None = None) -> torch.Tensor:
-    """The cross-attention byte mixin on top of the two embedding gathers (train_gpt.py:342-379, 446-464, 271-300):
-    tokens (1, T) -> (1, T, dim).  The reference asserts batch 1 (line 275).  fp32, forward only.
-    head_layout "as_viewed" reproduces the reference's reshape of k and v (lines 283-284); "per_token" is the
-    rearrange its comment names."""
-    if tokens.ndim == 1:
-        tokens = tokens[None]
-    assert tokens.shape[0] == 1, "Must use batch size = 1 for FlexAttention"      # train_gpt.py:275
-    params = (tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor)
-    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-        raise RuntimeError("mixture-of-tokenizers_amd: the cross-attention mixin is forward-only so far; call it under "
-                           "torch.no_grad() or with frozen parameters")
+def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
+                     bpt, n_heads, norm_tok, norm_byte, head_layout, eps):
+    """Validated MotCrossAttnDesc for both directions; returns (desc, keepalive list, device, T, D)."""
     dev = capi.require_device(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k)
     T = tokens.shape[1]
     tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
@@ -468,7 +454,6 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
     rot = [_contig(t, f32, "rotary buffer") for t in (cos_q, sin_q, cos_k, sin_k)]
     if any(r.ndim != 2 or r.shape[1] != 64 for r in rot):
         raise AssertionError("cross_attn: rotary buffers must be (len, 64)")
-    out = torch.empty((1, T, D), dtype=f32, device=dev)
     d = capi.MotCrossAttnDesc()
     d.struct_size = C.sizeof(capi.MotCrossAttnDesc)
     d.dtype, d.n_tokens, d.bpt, d.n_heads, d.dim = capi.F32, T, int(bpt), int(n_heads), D
@@ -480,10 +465,86 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
     d.cos_q, d.sin_q, d.cos_k, d.sin_k = (capi.ptr(r) for r in rot)
     d.rot_q_len, d.rot_k_len = rot[0].shape[0], rot[2].shape[0]
     d.eps = float(eps or 0.0)
-    d.out, d.status = capi.ptr(out), capi.ptr(capi.status_word(dev))
+    d.status = capi.ptr(capi.status_word(dev))
+    return d, [tok, tt, bt, qw, kvw, pw, lam, ia, ib] + rot, dev, T, D
+
+
+class _CrossAttnFn(torch.autograd.Function):
+    """One autograd node for the cross-attention mixin: forward = mot_cross_attn_fwd, backward = mot_cross_attn_bwd
+    (everything is recomputed from the inputs; dense fp32 gradients for the two tables, q_w, kv_w, c_proj and lambda)."""
+
+    @staticmethod
+    def forward(ctx, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, rot, kw):
+        ctx.save_for_backward(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, *rot)
+        ctx.kw = kw
+        return _cross_attn_fwd(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, *rot, **kw)
+
+    @staticmethod
+    def backward(ctx, gx):
+        tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, cq, sq, ck, sk = ctx.saved_tensors
+        g = cross_attn_backward(gx, tokens, ids_a, tok_table, byte_table, q_w=q_w, kv_w=kv_w, proj_w=proj_w, lambda_factor=lambda_factor,
+                                cos_q=cq, sin_q=sq, cos_k=ck, sin_k=sk, **ctx.kw)
+        return (g["tok_table"], g["byte_table"], g["q_w"], g["kv_w"], g["proj_w"], g["lambda_factor"].reshape(lambda_factor.shape),
+                None, None, None, None)
+
+
+@torch.compiler.disable
+def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
+                        bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None) -> dict:
+    """One call of mot_cross_attn_bwd: dense fp32 gradients {tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor}."""
+    if tokens.ndim == 1:
+        tokens = tokens[None]
+    d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
+                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps)
+    g = _contig(grad_out.reshape(T, D), torch.float32, "grad_out")
+    out = {"tok_table": torch.zeros_like(keep[1]), "byte_table": torch.zeros_like(keep[2]), "q_w": torch.zeros_like(keep[3]),
+           "kv_w": torch.zeros_like(keep[4]), "proj_w": torch.zeros_like(keep[5]), "lambda_factor": torch.zeros(1, dtype=torch.float32, device=dev)}
+    gr = capi.MotCrossAttnGrads()
+    gr.struct_size = C.sizeof(capi.MotCrossAttnGrads)
+    gr.grad_out = capi.ptr(g)
+    gr.d_tok_table, gr.d_byte_table = capi.ptr(out["tok_table"]), capi.ptr(out["byte_table"])
+    gr.d_q_w, gr.d_kv_w, gr.d_proj_w, gr.d_lambda = capi.ptr(out["q_w"]), capi.ptr(out["kv_w"]), capi.ptr(out["proj_w"]), capi.ptr(out["lambda_factor"])
+    ws = _workspace(dev, capi.lib.mot_cross_attn_bwd_workspace_bytes(C.byref(d)))
+    if ws is not None:
+        d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
+    capi.check(capi.lib.mot_cross_attn_bwd(C.byref(d), C.byref(gr), capi.stream_of(dev)))
+    capi.after_call(dev)
+    return out
+
+
+def _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k, *,
+                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None):
+    d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
+                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps)
+    out = torch.empty((1, T, D), dtype=torch.float32, device=dev)
+    d.out = capi.ptr(out)
     ws = _workspace(dev, capi.lib.mot_cross_attn_workspace_bytes(C.byref(d)))
     if ws is not None:
         d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
     capi.check(capi.lib.mot_cross_attn_fwd(C.byref(d), capi.stream_of(dev)))
     capi.after_call(dev)
     return out
+
+
+@torch.compiler.disable
+def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor, *,
+               q_w: torch.Tensor, kv_w: torch.Tensor, proj_w: torch.Tensor, lambda_factor: torch.Tensor,
+               cos_q: torch.Tensor, sin_q: torch.Tensor, cos_k: torch.Tensor, sin_k: torch.Tensor,
+               bpt: int, n_heads: int, ids_b: torch.Tensor | None = None, norm_tok: bool = True, norm_byte: bool = True,
+               head_layout: str = "as_viewed", eps: float | None = None) -> torch.Tensor:
+    """The cross-attention byte mixin on top of the two embedding gathers (train_gpt.py:342-379, 446-464, 271-300):
+    tokens (1, T) -> (1, T, dim).  The reference asserts batch 1 (line 275).  fp32.  With autograd enabled and
+    differentiable parameters it records one backward node (one id tensor; the two-id-tensor embedding is forward-only).
+    head_layout "as_viewed" reproduces the reference's reshape of k and v (lines 283-284); "per_token" is the
+    rearrange its comment names."""
+    if tokens.ndim == 1:
+        tokens = tokens[None]
+    assert tokens.shape[0] == 1, "Must use batch size = 1 for FlexAttention"      # train_gpt.py:275
+    kw = dict(bpt=bpt, n_heads=n_heads, norm_tok=norm_tok, norm_byte=norm_byte, head_layout=head_layout, eps=eps)
+    params = (tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor)
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if ids_b is not None:
+            raise RuntimeError("mixture-of-tokenizers_amd: the cross-attention mixin over norm(emb(padded) + emb(pulled)) is forward-only; "
+                               "call it under torch.no_grad() or with frozen parameters")
+        return _CrossAttnFn.apply(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, (cos_q, sin_q, cos_k, sin_k), kw)
+    return _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k, **kw)
