@@ -236,7 +236,7 @@ int mot_embed_mix_fwd(const MotEmbedMixDesc *desc /* host */, mot_stream_t strea
  * Each token attends to its own `bpt` byte embeddings: q = q_w xq, (k, v) = kv_w xkv, per-head rms-norm of q and
  * k, RoPE with the position in each one's own sequence, v *= lambda, softmax(q.k / sqrt(hd)) over the bpt
  * keys, out = proj_w y.  The reference asserts batch 1 (line 275): tokens is one row of n_tokens.
- * head_dim is 128 (line 459); dim = token_dim = byte_dim = model_dim (line 449).  fp32, forward only.
+ * head_dim is 128 (line 459); dim = token_dim = byte_dim = model_dim (line 449).  fp32.
  * head_layout MOT_HEADS_AS_VIEWED reproduces lines 283-284 (k, v are reshaped, not transposed, into
  * (H, T, bpt, hd)); MOT_HEADS_PER_TOKEN is the einops expression in the comment of those lines.
  * cos/sin are the Rotary buffers of the module (lines 190-197), fp32 [len, 64], built by the caller.

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--layout", default="as_viewed")
     ap.add_argument("--dual", action="store_true")
+    ap.add_argument("--backward", action="store_true", help="time forward + backward through autograd")
     a = ap.parse_args()
     import mixture_of_tokenizers_amd as mot
     from mixture_of_tokenizers_amd.modules import Rotary
@@ -42,18 +43,30 @@ def main():
     rq, rk = Rotary(128, T).to(dev), Rotary(128, T * bpt).to(dev)
     kw = dict(q_w=q_w, kv_w=kv_w, proj_w=p_w, lambda_factor=torch.tensor(0.5, device=dev), cos_q=rq.cos, sin_q=rq.sin,
               cos_k=rk.cos, sin_k=rk.sin, bpt=bpt, n_heads=H, head_layout=a.layout, ids_b=padded if a.dual else None)
+    if a.backward:
+        for t in (Et, Eb, q_w, kv_w, p_w, kw["lambda_factor"]):
+            t.requires_grad_(True)
+        go = torch.randn((1, T, D), generator=g, device=dev)
+
+        def run():
+            x = mot.functional.cross_attn(toks, pulled, Et, Eb, **kw)
+            x.backward(go)
+            return x
+    else:
+        def run():
+            return mot.functional.cross_attn(toks, pulled, Et, Eb, **kw)
     for _ in range(3):
-        x = mot.functional.cross_attn(toks, pulled, Et, Eb, **kw)
+        x = run()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(a.steps):
-        x = mot.functional.cross_attn(toks, pulled, Et, Eb, **kw)
+        x = run()
     e1.record(); torch.cuda.synchronize()
     mot.check_status()
     ms = e0.elapsed_time(e1) / a.steps
     flops = 2.0 * T * D * D * 2 + (2.0 * T * bpt * D * D * 2 if a.dual else 2.0 * 458 * D * D * 2)
-    print(json.dumps({"workload": f"cross_attn T={T} d={D} bpt={bpt} heads={H} layout={a.layout} dual={a.dual}", "ms": ms,
+    print(json.dumps({"backward": a.backward, "workload": f"cross_attn T={T} d={D} bpt={bpt} heads={H} layout={a.layout} dual={a.dual}", "ms": ms,
                       "tokens_per_s": T / (ms * 1e-3), "gemm_tflops": flops / (ms * 1e-3) / 1e12,
                       "reference_flops_ratio": (2.0 * T * D * D * 2 + 2.0 * T * bpt * D * D * 2) / flops,
                       "finite": bool(torch.isfinite(x).all())}))
