@@ -168,3 +168,35 @@ def test_cross_attn_backward_vs_oracle(mot, D, bpt, Vt, T, layout, norms, seed):
     for p, key in ((pEt, "tok_table"), (pEb, "byte_table"), (pq, "q_w"), (pkv, "kv_w"), (pp, "proj_w")):
         assert grel(host(p.grad), ref[key]) < GTOL, key
     assert abs(float(plam.grad) - ref["lambda_factor"][0]) < GTOL * max(1.0, abs(ref["lambda_factor"][0]))
+
+
+def test_cross_attn_locality_at_size(mot):
+    """T = 16 384 (beyond what the oracle is run on): with head_layout="per_token" a byte of token t only influences output
+    row t, and a token id only its own row; with the reference's "as_viewed" reshape (more than one head) a byte reaches
+    the rows of other tokens -- and exactly the (head, token) pairs the reshape maps its (position, head) rows to."""
+    from mixture_of_tokenizers_amd.modules import Rotary
+    T, D, bpt, Vt = 16384, 256, 8, 1000
+    H = D // 128
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    Et, Eb = torch.randn((Vt, D), generator=gen, device=DEV), torch.randn((gi.BYTE_VOCAB, D), generator=gen, device=DEV)
+    q_w, kv_w, p_w = (dev(f32(a)) for a in gi.cross_weights(77, D))
+    toks = torch.randint(0, Vt, (1, T), generator=gen, device=DEV, dtype=torch.int32)
+    ids = torch.randint(0, 256, (1, T * bpt), generator=gen, device=DEV, dtype=torch.int64)
+    rq, rk = Rotary(128, T).to(DEV), Rotary(128, T * bpt).to(DEV)
+    kw = dict(q_w=q_w, kv_w=kv_w, proj_w=p_w, lambda_factor=torch.tensor(0.5, device=DEV), cos_q=rq.cos, sin_q=rq.sin, cos_k=rk.cos, sin_k=rk.sin,
+              bpt=bpt, n_heads=H)
+    t_mod, c_mod = 9001, 3
+    ids2 = ids.clone(); ids2[0, t_mod * bpt + c_mod] = (ids[0, t_mod * bpt + c_mod] + 1) % 256
+    with torch.no_grad():
+        for layout in ("per_token", "as_viewed"):
+            a = mot.functional.cross_attn(toks, ids, Et, Eb, head_layout=layout, **kw)[0]
+            b = mot.functional.cross_attn(toks, ids2, Et, Eb, head_layout=layout, **kw)[0]
+            assert bool(torch.isfinite(a).all())
+            changed = set(torch.nonzero((a != b).any(dim=1)).view(-1).tolist())
+            if layout == "per_token":
+                assert changed == {t_mod}
+            else:   # kv position p, head hk sits in flat row r = p*H + hk, which query (h, t) = divmod(r // bpt, T) reads
+                p = t_mod * bpt + c_mod
+                expect = {((p * H + hk) // bpt) % T for hk in range(H)}
+                assert changed == expect and changed != {t_mod}
+    mot.check_status()

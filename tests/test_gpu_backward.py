@@ -292,3 +292,46 @@ def test_noop_backward_vs_oracle(mot, D, Vt, B, T, norm_tok, scaled, seed):
         assert abs(float(got["scale_tok"]) - ref["scales"][0]) < TOL * max(abs(ref["scales"][0]), 1.0)
     touched = np.zeros(Vt, bool); touched[toks.reshape(-1)] = True
     assert not host(got["tok_table"])[~touched].any()          # rows no token touched get exactly zero gradient
+
+
+def test_full_size_backward_properties(mot):
+    """Config-4 size (256 x 2048 tokens, GPT-2 vocab, d 768, bpt 16), where the oracle is too slow to run whole:
+    size-independent properties of the backward -- it is linear in the upstream gradient, rows of tokens that do not
+    occur stay exactly zero, the byte-table gradient's column sums equal the column sums of the per-position byte
+    gradients (= of dx, folded over the 16 slots), and 16 sampled rows of the token-table gradient match the oracle
+    evaluated on the positions of those tokens alone."""
+    B, T, Vt, D, Db, bpt = 256, 2048, 50257, 768, 48, 16
+    toks_np = gi.fineweb_like_tokens(12345, B, T, vocab=Vt)
+    tab = gi.widen_left_pad(gi.load_real_ttb8(), bpt)
+    toks = dev(toks_np)
+    ids = mot.data_creation.pull_from_left(mot.data_creation.tokens_to_bytes(toks, dev(tab)), bpt, gi.PAD, gi.EOT)
+    gen = torch.Generator(device=DEV).manual_seed(7)
+    Et = torch.randn((Vt, D), generator=gen, device=DEV)
+    Eb = torch.randn((gi.BYTE_VOCAB, Db), generator=gen, device=DEV)
+    g1 = torch.randn((B, T, D), generator=gen, device=DEV)
+    g2 = torch.randn((B, T, D), generator=gen, device=DEV)
+    bw = lambda g: mot.functional.embed_mix_backward(g, toks, Et, Eb, mode="sum", bpt=bpt, ids_a=ids, norm_out=True)
+    r1, r2, r12 = bw(g1), bw(g2), bw(g1 + g2)
+    mot.check_status()
+    for k in ("tok_table", "byte_table"):
+        a, b = r12[k], r1[k] + r2[k]
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), k               # linearity
+    counts = torch.bincount(toks.view(-1).long(), minlength=Vt)
+    assert float(r1["tok_table"][counts == 0].abs().max()) == 0.0                            # untouched rows
+    # column sums: sum_rows d_byte[:, wi] == sum over positions and slots of dx[n, k*Db + wi]; dx itself is what a backward
+    # with a single-row "token table" view returns summed per token, i.e. the column sums of d_tok folded over the slots
+    col_tok = r1["tok_table"].double().sum(0).view(bpt, Db).sum(0)
+    col_byte = r1["byte_table"].double().sum(0)
+    assert float((col_tok - col_byte).abs().max()) <= 2e-5 * float(col_byte.abs().max())
+    # a few token rows against the oracle on just their positions (the gradient of a row only involves its own positions)
+    flat = toks_np.reshape(-1)
+    ids_np, g_np = host(ids).reshape(-1, bpt), host(g1).reshape(-1, D)
+    Et_np, Eb_np = host(Et).astype(np.float64), host(Eb).astype(np.float64)
+    for tok in (0, 1, 17, 262, 1000, 5000, 20000, 50255):
+        pos = np.flatnonzero(flat == tok)[:64]
+        if len(pos) == 0:
+            continue
+        sub = orc.embed_mix_bwd(flat[pos][None], ids_np[pos].reshape(1, -1), None, Et_np, Eb_np, g_np[pos][None].astype(np.float64),
+                                mode="sum", bpt=bpt, dtype=np.float64, norm_out=True)
+        if len(np.flatnonzero(flat == tok)) <= 64:      # all of the token's positions were included: its row must match
+            assert rel(host(r1["tok_table"][tok]), sub["tok_table"][tok]) < TOL, tok
