@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 6
+#define MOT_ABI_VERSION 7
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -268,11 +268,15 @@ typedef struct MotCrossAttnDesc {
     const float *cos_k, *sin_k; /* [>= n_tokens * bpt, 64] */
     int64_t rot_q_len, rot_k_len; /* rows of the two pairs of buffers (line 200 asserts they suffice) */
     float eps;                /* 0 = finfo(float32).eps */
-    int32_t reserved;
+    int32_t kv_tables_ready;  /* forward, one id tensor: 1 = `kv_tables` already holds this call's tables (skip building them) */
     void *out;                /* [n_tokens, dim] */
     uint32_t *status;         /* optional, as in MotEmbedMixDesc */
     void *workspace;          /* mot_cross_attn_workspace_bytes(desc) */
     size_t workspace_bytes;
+    /* optional, forward with one id tensor: caller-kept buffer of 2 * byte_rows * n_heads * 128 floats for the per-byte-row
+     * key / value tables.  They depend on byte_table, kv_w and lambda_factor only, so an inference loop builds them once:
+     * pass the buffer with kv_tables_ready = 0 after those change (the call fills it), = 1 otherwise. */
+    void *kv_tables;
 } MotCrossAttnDesc;
 
 /*

@@ -194,6 +194,11 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     const size_t lin_bytes = L.lin_floats * 4;
     const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
     const bool dual = d.ids_b != nullptr;
+    const bool kv_cached = !dual && d.kv_tables != nullptr;
+    if (kv_cached) {   // caller-kept tables: built by this call unless it says they are current
+        kt = (float *)d.kv_tables;
+        vt = kt + (size_t)L.R * HD;
+    }
     const int64_t n_iota = T > L.R ? T : L.R;
     int rc;
     hipLaunchKernelGGL(iota32_kernel, dim3(256), dim3(kThreads), 0, stream, iota, n_iota);
@@ -214,17 +219,19 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
         kv_rows = xkv;
         kv_norm = 0;
     }
-    const float *kv_w = (const float *)d.kv_w;
-    dense_desc(g, iota, byte0, kv_rows, L.R, L.R, D, kv_w, HD, kt, d.status, lin, lin_bytes);
-    g.norm_tok = kv_norm; g.eps = eps;
-    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
-    dense_desc(g, iota, byte0, kv_rows, L.R, L.R, D, kv_w + (size_t)HD * D, HD, vt, d.status, lin, lin_bytes);
-    g.norm_tok = kv_norm; g.eps = eps;
-    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
-    const int64_t kvw = L.R * H;
-    hipLaunchKernelGGL(kv_finish_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kt, vt, L.R, H,
-                       d.lambda_factor, eps);
-    if ((rc = check_launch("kv_finish_kernel"))) return rc;
+    if (!(kv_cached && d.kv_tables_ready)) {
+        const float *kv_w = (const float *)d.kv_w;
+        dense_desc(g, iota, byte0, kv_rows, L.R, L.R, D, kv_w, HD, kt, d.status, lin, lin_bytes);
+        g.norm_tok = kv_norm; g.eps = eps;
+        if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+        dense_desc(g, iota, byte0, kv_rows, L.R, L.R, D, kv_w + (size_t)HD * D, HD, vt, d.status, lin, lin_bytes);
+        g.norm_tok = kv_norm; g.eps = eps;
+        if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+        const int64_t kvw = L.R * H;
+        hipLaunchKernelGGL(kv_finish_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kt, vt, L.R, H,
+                           d.lambda_factor, eps);
+        if ((rc = check_launch("kv_finish_kernel"))) return rc;
+    }
     // 3. attention of every token over its own bpt keys
     AttnArgs A;
     A.q = q; A.y = y; A.kt = kt; A.vt = vt; A.ids = dual ? nullptr : d.ids_a; A.rows = L.R; A.T = T; A.bpt = d.bpt; A.H = H;

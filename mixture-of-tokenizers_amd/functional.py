@@ -513,11 +513,19 @@ def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, 
 
 
 def _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k, *,
-                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None):
+                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None):
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
                                           bpt, n_heads, norm_tok, norm_byte, head_layout, eps)
     out = torch.empty((1, T, D), dtype=torch.float32, device=dev)
     d.out = capi.ptr(out)
+    if kv_cache is not None and ids_b is None:
+        # the per-byte-row key / value tables depend on (byte_table, kv_w, lambda_factor) only: kept across calls while those are unchanged
+        key = tuple((t.data_ptr(), t._version) for t in (byte_table, kv_w, lambda_factor)) + (bool(norm_byte), float(eps or 0.0), str(dev))
+        n = 2 * keep[2].shape[0] * n_heads * 128
+        if kv_cache.get("buf") is None or kv_cache["buf"].numel() != n or kv_cache["buf"].device != dev:
+            kv_cache["buf"], kv_cache["key"] = torch.empty(n, dtype=torch.float32, device=dev), None
+        d.kv_tables, d.kv_tables_ready = capi.ptr(kv_cache["buf"]), int(kv_cache.get("key") == key)
+        kv_cache["key"] = key
     ws = _workspace(dev, capi.lib.mot_cross_attn_workspace_bytes(C.byref(d)))
     if ws is not None:
         d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
@@ -531,7 +539,7 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
                q_w: torch.Tensor, kv_w: torch.Tensor, proj_w: torch.Tensor, lambda_factor: torch.Tensor,
                cos_q: torch.Tensor, sin_q: torch.Tensor, cos_k: torch.Tensor, sin_k: torch.Tensor,
                bpt: int, n_heads: int, ids_b: torch.Tensor | None = None, norm_tok: bool = True, norm_byte: bool = True,
-               head_layout: str = "as_viewed", eps: float | None = None) -> torch.Tensor:
+               head_layout: str = "as_viewed", eps: float | None = None, kv_cache: dict | None = None) -> torch.Tensor:
     """The cross-attention byte mixin on top of the two embedding gathers (train_gpt.py:342-379, 446-464, 271-300):
     tokens (1, T) -> (1, T, dim).  The reference asserts batch 1 (line 275).  fp32.  With autograd enabled and
     differentiable parameters it records one backward node (one id tensor; the two-id-tensor embedding is forward-only).
@@ -547,4 +555,7 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
             raise RuntimeError("mixture-of-tokenizers_amd: the cross-attention mixin over norm(emb(padded) + emb(pulled)) is forward-only; "
                                "call it under torch.no_grad() or with frozen parameters")
         return _CrossAttnFn.apply(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, (cos_q, sin_q, cos_k, sin_k), kw)
-    return _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k, **kw)
+    # `kv_cache` (a dict the caller keeps, e.g. on the module): inference calls reuse the per-byte-row K/V tables while the
+    # byte table, kv_w and lambda_factor are unchanged (tensor versions are checked)
+    return _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
+                           kv_cache=kv_cache, **kw)

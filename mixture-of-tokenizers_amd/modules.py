@@ -269,6 +269,7 @@ class CrossAttention(nn.Module):
         self.rotary_k = Rotary(head_dim, max_seq_len_kv)
         self.c_proj = CastedLinear(hdim, dim)
         self.attn_scale = 0.12   # kept for state parity; the reference's forward divides by sqrt(head_dim) instead (line 286)
+        self._kv_cache: dict = {}   # per-byte-row K/V tables, reused by no-grad calls while the parameters are unchanged
 
     def forward(self, xq, xkv=None) -> Tensor:
         if not isinstance(xq, EmbedHandle):
@@ -279,7 +280,8 @@ class CrossAttention(nn.Module):
         return F_mot.cross_attn(h.tokens, h.ids_a, _f32(h.tok_weight, "token table"), _f32(h.byte_weight, "byte table"),
                                 ids_b=h.ids_b, q_w=self.q_w, kv_w=self.kv_w, proj_w=self.c_proj.weight, lambda_factor=self.lambda_factor,
                                 cos_q=self.rotary_q.cos, sin_q=self.rotary_q.sin, cos_k=self.rotary_k.cos, sin_k=self.rotary_k.sin,
-                                bpt=h.bpt, n_heads=self.num_heads, norm_tok=h.norm_tok, norm_byte=h.norm_byte, head_layout=self.head_layout)
+                                bpt=h.bpt, n_heads=self.num_heads, norm_tok=h.norm_tok, norm_byte=h.norm_byte, head_layout=self.head_layout,
+                                kv_cache=self._kv_cache)
 
 
 class ByteMixinCrossAttn(nn.Module):  # train_gpt.py:446-464

@@ -200,3 +200,30 @@ def test_cross_attn_locality_at_size(mot):
                 expect = {((p * H + hk) // bpt) % T for hk in range(H)}
                 assert changed == expect and changed != {t_mod}
     mot.check_status()
+
+
+def test_cross_attn_kv_table_cache(mot):
+    """No-grad calls through the module keep the per-byte-row K/V tables while byte table, kv_w and lambda are unchanged
+    (tensor versions), and rebuild them after an in-place update."""
+    from mixture_of_tokenizers_amd import modules as M
+    name, Vt, D, bpt, T, seed = gi.CROSS_CASES[1]
+    z = np.load(G / "cross_attn.npz")
+    embed, mixin = build(M, Vt, D, bpt, T, seed, "pulled")
+    args = dict(tokens=dev(z[f"{name}/tokens"]), byte_tensor=dev(z[f"{name}/padded"]), byte_tensor_pulled=dev(z[f"{name}/pulled"]))
+    ca = mixin.mixin.mixin
+    with torch.no_grad():
+        a = mixin(*embed(**args))
+        key1 = ca._kv_cache["key"]
+        b = mixin(*embed(**args))                       # second call: tables reused
+        assert ca._kv_cache["key"] == key1 and torch.equal(a, b)
+        ca.kv_w.mul_(1.5)                               # in-place update bumps the version: tables rebuilt
+        c = mixin(*embed(**args))
+        assert ca._kv_cache["key"] != key1 and not torch.equal(a, c)
+        fresh = mot.functional.cross_attn(args["tokens"], args["byte_tensor_pulled"], embed.embed_tokens.weight, embed.embed_bytes.weight,
+                                          q_w=ca.q_w, kv_w=ca.kv_w, proj_w=ca.c_proj.weight, lambda_factor=ca.lambda_factor,
+                                          cos_q=ca.rotary_q.cos, sin_q=ca.rotary_q.sin, cos_k=ca.rotary_k.cos, sin_k=ca.rotary_k.sin,
+                                          bpt=bpt, n_heads=D // 128)
+        assert torch.equal(c, fresh)
+        ca.lambda_factor.fill_(0.9)
+        d = mixin(*embed(**args))
+        assert not torch.equal(c, d)

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--layout", default="as_viewed")
     ap.add_argument("--dual", action="store_true")
     ap.add_argument("--backward", action="store_true", help="time forward + backward through autograd")
+    ap.add_argument("--kv-cache", action="store_true", help="inference: keep the per-byte-row K/V tables across calls")
     a = ap.parse_args()
     import mixture_of_tokenizers_amd as mot
     from mixture_of_tokenizers_amd.modules import Rotary
@@ -53,8 +54,11 @@ def main():
             x.backward(go)
             return x
     else:
+        cache = {} if a.kv_cache else None
+
         def run():
-            return mot.functional.cross_attn(toks, pulled, Et, Eb, **kw)
+            with torch.no_grad():
+                return mot.functional.cross_attn(toks, pulled, Et, Eb, kv_cache=cache, **kw)
     for _ in range(3):
         x = run()
     torch.cuda.synchronize()
