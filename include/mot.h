@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 7
+#define MOT_ABI_VERSION 8
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -277,6 +277,9 @@ typedef struct MotCrossAttnDesc {
      * key / value tables.  They depend on byte_table, kv_w and lambda_factor only, so an inference loop builds them once:
      * pass the buffer with kv_tables_ready = 0 after those change (the call fills it), = 1 otherwise. */
     void *kv_tables;
+    /* optional: buffer of 2 * n_tokens * n_heads * 128 floats.  The forward leaves the projected queries and the attention
+     * output there; the backward, given the same buffer, reads them instead of recomputing that part of the forward. */
+    void *saved_qy;
 } MotCrossAttnDesc;
 
 /*

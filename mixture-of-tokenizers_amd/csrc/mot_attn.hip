@@ -194,6 +194,10 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     const size_t lin_bytes = L.lin_floats * 4;
     const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
     const bool dual = d.ids_b != nullptr;
+    if (d.saved_qy) {   // kept for the backward
+        q = (float *)d.saved_qy;
+        y = q + (size_t)T * HD;
+    }
     const bool kv_cached = !dual && d.kv_tables != nullptr;
     if (kv_cached) {   // caller-kept tables: built by this call unless it says they are current
         kt = (float *)d.kv_tables;
@@ -520,11 +524,16 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     if (e == hipSuccess) e = hipMemsetAsync(dkn_tab, 0, (size_t)R * HD * 4, stream);
     if (e == hipSuccess) e = hipMemsetAsync(dvl_tab, 0, (size_t)R * HD * 4, stream);
     if (e != hipSuccess) return set_error(MOT_EHIP, "cross_attn_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-    // ---- forward recompute
+    // ---- forward recompute (the queries and the attention output come from the forward when it kept them)
     MotEmbedMixDesc g;
-    dense_desc(g, d.tokens, byte0, d.tok_table, d.tok_rows, T, D, d.q_w, HD, q, d.status, lin, lin_bytes);
-    g.norm_tok = d.norm_tok; g.eps = eps;
-    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+    if (d.saved_qy) {
+        q = (float *)d.saved_qy;
+        y = q + (size_t)T * HD;
+    } else {
+        dense_desc(g, d.tokens, byte0, d.tok_table, d.tok_rows, T, D, d.q_w, HD, q, d.status, lin, lin_bytes);
+        g.norm_tok = d.norm_tok; g.eps = eps;
+        if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+    }
     const float *kv_w = (const float *)d.kv_w;
     dense_desc(g, iota, byte0, d.byte_table, R, R, D, kv_w, HD, kpre, d.status, lin, lin_bytes);
     g.norm_tok = d.norm_byte; g.eps = eps;
@@ -539,8 +548,10 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     A.q = q; A.y = y; A.kt = kn; A.vt = vl; A.ids = d.ids_a; A.rows = R; A.T = T; A.bpt = d.bpt; A.H = H;
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
     const int64_t waves = T * H;
-    hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
-    if ((rc = check_launch("cross_attn_kernel"))) return rc;
+    if (!d.saved_qy) {
+        hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
+        if ((rc = check_launch("cross_attn_kernel"))) return rc;
+    }
     // ---- c_proj:  dW_p += g^T y;  dy = g W_p   (proj_w [D, HD] is the k-major operand of g[T, D] -> dy[T, HD])
     if (gr.d_proj_w && (rc = launch_gemm_tn(g_out, D, D, y, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
     if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, wk, iota, byte0, d.status, stream))) return rc;

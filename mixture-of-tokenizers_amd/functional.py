@@ -475,23 +475,26 @@ class _CrossAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, rot, kw):
-        ctx.save_for_backward(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, *rot)
+        # the projected queries and the attention output are kept for the backward (2 x T x hdim floats)
+        saved = torch.empty(2 * tokens.shape[-1] * kw["n_heads"] * 128, dtype=torch.float32, device=tok_table.device)
+        ctx.save_for_backward(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, saved, *rot)
         ctx.kw = kw
-        return _cross_attn_fwd(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, *rot, **kw)
+        return _cross_attn_fwd(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, *rot, saved_qy=saved, **kw)
 
     @staticmethod
     def backward(ctx, gx):
-        tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, cq, sq, ck, sk = ctx.saved_tensors
+        tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, saved, cq, sq, ck, sk = ctx.saved_tensors
         g = cross_attn_backward(gx, tokens, ids_a, tok_table, byte_table, q_w=q_w, kv_w=kv_w, proj_w=proj_w, lambda_factor=lambda_factor,
-                                cos_q=cq, sin_q=sq, cos_k=ck, sin_k=sk, **ctx.kw)
+                                cos_q=cq, sin_q=sq, cos_k=ck, sin_k=sk, saved_qy=saved, **ctx.kw)
         return (g["tok_table"], g["byte_table"], g["q_w"], g["kv_w"], g["proj_w"], g["lambda_factor"].reshape(lambda_factor.shape),
                 None, None, None, None)
 
 
 @torch.compiler.disable
 def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                        bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None) -> dict:
-    """One call of mot_cross_attn_bwd: dense fp32 gradients {tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor}."""
+                        bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, saved_qy=None) -> dict:
+    """One call of mot_cross_attn_bwd: dense fp32 gradients {tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor}.
+    `saved_qy`: the buffer the forward filled (projected queries + attention output); without it they are recomputed."""
     if tokens.ndim == 1:
         tokens = tokens[None]
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
@@ -504,6 +507,8 @@ def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, 
     gr.grad_out = capi.ptr(g)
     gr.d_tok_table, gr.d_byte_table = capi.ptr(out["tok_table"]), capi.ptr(out["byte_table"])
     gr.d_q_w, gr.d_kv_w, gr.d_proj_w, gr.d_lambda = capi.ptr(out["q_w"]), capi.ptr(out["kv_w"]), capi.ptr(out["proj_w"]), capi.ptr(out["lambda_factor"])
+    if saved_qy is not None:
+        d.saved_qy = capi.ptr(_contig(saved_qy, torch.float32, "saved_qy"))
     ws = _workspace(dev, capi.lib.mot_cross_attn_bwd_workspace_bytes(C.byref(d)))
     if ws is not None:
         d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
@@ -513,11 +518,13 @@ def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, 
 
 
 def _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k, *,
-                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None):
+                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None, saved_qy=None):
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
                                           bpt, n_heads, norm_tok, norm_byte, head_layout, eps)
     out = torch.empty((1, T, D), dtype=torch.float32, device=dev)
     d.out = capi.ptr(out)
+    if saved_qy is not None:
+        d.saved_qy = capi.ptr(saved_qy)
     if kv_cache is not None and ids_b is None:
         # the per-byte-row key / value tables depend on (byte_table, kv_w, lambda_factor) only: kept across calls while those are unchanged
         key = tuple((t.data_ptr(), t._version) for t in (byte_table, kv_w, lambda_factor)) + (bool(norm_byte), float(eps or 0.0), str(dev))
