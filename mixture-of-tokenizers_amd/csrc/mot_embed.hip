@@ -11,6 +11,8 @@
 //            rms-norm reductions are wave shuffles, the mixed row is written once with
 //            non-temporal 16 B stores.  Algorithmic traffic: 4 + 2*bpt + 4*Dt B read and
 //            4*Dm B written per token; HBM-bound.
+#include <stdlib.h>
+
 #include "mot_mix.hpp"
 
 namespace mot {
@@ -330,6 +332,111 @@ static int dispatch_nch(const MixArgs &A, int dtype, int64_t blocks, size_t lds,
     }
 }
 
+
+// ------------------------------------------------------------------------------------------ MEAN with the character table in LDS
+// x = s_t * E_tok[t] + s_c * mean_k E_char[c_k]   (inference/inference.py:266-267, 323-327; config 5: 128 k token vocab, 132
+// characters, d 2048, 8 character slots).  With whole rows per token, the eight 8 KB character rows of every token come out
+// of L2 -- 64 KB of L2 reads against 16 KB of HBM traffic, and the kernel ran at the L2 rate (35 % of the HBM roofline).
+// The character table is small (132 x 2048) but does not fit LDS whole; a COLUMN SLICE of it does (132 rows x 256 fp32
+// columns = 135 KB of the 160 KB).  So a workgroup owns one slice, keeps it in LDS for its whole life, and streams the same
+// slice of the token rows and of the output: the character rows are read from HBM/L2 once per workgroup instead of eight
+// times per token.  1024 threads (16 waves share the slice: one workgroup per CU by LDS), one wave per token, U tokens in flight.
+template <typename T, int U>
+__global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, int slice_cols, int nslices, int64_t tokens_per_part) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *tab = (T *)lds_raw;                                   // [byte_rows][slice_cols]
+    constexpr int VEC = Elem<T>::kVec;
+    typedef typename Elem<T>::vec vec_t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.x % nslices;
+    const int64_t part = blockIdx.x / nslices;
+    const int col0 = slice * slice_cols;
+    const int D = A.Dt;
+    const T *byte_table = (const T *)A.byte_table, *tok_table = (const T *)A.tok_table;
+    const int pieces_per_row = slice_cols / VEC;              // 16-byte pieces
+    for (int64_t q = tid; q < A.byte_rows * pieces_per_row; q += 1024) {
+        const int r = (int)(q / pieces_per_row), c = (int)(q - (int64_t)r * pieces_per_row) * VEC;
+        *(typename Elem<T>::raw *)(tab + (size_t)r * slice_cols + c) = Elem<T>::load_raw(byte_table + (int64_t)r * D + col0 + c);
+    }
+    __syncthreads();
+    const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
+    const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
+    const float inv_bpt = 1.0f / (float)A.bpt;
+    const int64_t n_all = A.T;                                // tokens are addressed flat: A.T = n_rows * tokens_per_row here
+    const int64_t n0 = part * tokens_per_part, n1 = min(n_all, n0 + tokens_per_part);
+    const int nch = slice_cols / (64 * VEC);                  // 16-byte chunks per lane (1 for the built shapes... general loop below)
+    T *out = (T *)A.out;
+    for (int64_t tb = n0 + wave * U; tb < n1; tb += 16 * U) {
+        for (int ch = 0; ch < nch; ++ch) {
+            const int c = (lane + 64 * ch) * VEC;
+            typename Elem<T>::raw ar[U];
+            int idv[U];   // lanes < bpt: the token's character ids (one coalesced load; handed out by readlane below)
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t n = min(tb + u, n1 - 1);
+                int64_t cid = lane < A.bpt ? A.ids_a[n * A.bpt + lane] : 0;
+                if ((uint64_t)cid >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); cid = 0; }
+                idv[u] = (int)cid;
+                int tok = A.tokens[n];
+                if ((uint64_t)(uint32_t)tok >= (uint64_t)A.tok_rows) {
+                    if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
+                    tok = 0;
+                }
+                ar[u] = Elem<T>::load_raw(tok_table + (int64_t)tok * D + col0 + c);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t n = tb + u;
+                if (n >= n1) break;
+                vec_t acc = (vec_t)(0.f);
+                for (int k = 0; k < A.bpt; ++k) {             // chars.mean(dim=-2), inference.py:267
+                    const int id = __shfl(idv[u], k, 64);
+                    vec_t v = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)id * slice_cols + c));
+                    if (A.norm_byte) v *= A.byte_rnorm[id];
+                    acc += v;
+                }
+                vec_t a = Elem<T>::widen(ar[u]);
+                if (A.scale_tok) a *= s_tok;
+                const vec_t b = acc * inv_bpt;                // exact for the power-of-two slot counts of the reference (8), else within an ulp of acc / bpt
+                const vec_t x = a + (A.scale_byte ? b * s_byte : b);
+                Elem<T>::storev_nt(out + n * D + col0 + c, x);
+            }
+        }
+    }
+}
+
+template <typename T>
+static int launch_mean_lds(MixArgs A, const MotEmbedMixDesc &d, int slice_cols, hipStream_t stream) {
+    const int nslices = d.tok_dim / slice_cols;
+    const int64_t N = d.n_rows * d.tokens_per_row;
+    int64_t parts = 256 / nslices;                            // one persistent workgroup per CU
+    if (parts < 1) parts = 1;
+    const int64_t per = ((N + parts - 1) / parts + 63) & ~(int64_t)63;
+    parts = (N + per - 1) / per;
+    A.T = N;                                                  // flat token addressing (rows are independent without a pull)
+    const size_t lds = (size_t)d.byte_rows * slice_cols * sizeof(T);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)embed_mean_lds_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mean_lds_kernel): %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((embed_mean_lds_kernel<T, 4>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
+    return check_launch("embed_mean_lds_kernel");
+}
+
+// slice width (columns) for the LDS-table MEAN kernel, or 0 when the shape does not qualify
+static int mean_lds_slice(const MotEmbedMixDesc &d) {
+    if (d.mode != MOT_MIX_MEAN || d.id_source != MOT_IDS_GIVEN || d.ids_b || d.norm_tok || d.norm_out || d.counters || d.out_ids_padded ||
+        d.out_ids_pulled || getenv("MOT_NO_MEAN_LDS"))
+        return 0;
+    const int esize = d.dtype == MOT_BF16 ? 2 : 4, chunk = 64 * (16 / esize);   // columns one wave covers with 16-byte lanes
+    if (d.tok_dim % chunk || d.n_rows * d.tokens_per_row < 16384) return 0;
+    const size_t budget = 144 * 1024;
+    if ((size_t)d.byte_rows * chunk * esize > budget) return 0;
+    return chunk;   // one chunk per slice: the most slices, the smallest table image
+}
+
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
     MixArgs A;
     fill_mix_args(A, d);
@@ -350,6 +457,9 @@ int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
         int rc = launch_rows_rnorm(d.byte_table, d.byte_rows, d.byte_dim, A.eps, rn, d.dtype, stream);
         if (rc) return rc;
         A.byte_rnorm = rn;
+    }
+    if (const int sc = mean_lds_slice(d)) {
+        return d.dtype == MOT_BF16 ? launch_mean_lds<__bf16>(A, d, sc, stream) : launch_mean_lds<float>(A, d, sc, stream);
     }
     switch (d.mode) {
         case MOT_MIX_NOOP: return dispatch_nch<MOT_MIX_NOOP>(A, d.dtype, blocks, lds, stream);
