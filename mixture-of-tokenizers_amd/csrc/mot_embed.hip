@@ -387,19 +387,30 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t n = tb + u;
-                if (n >= n1) break;
-                vec_t acc = (vec_t)(0.f);
-                for (int k = 0; k < A.bpt; ++k) {             // chars.mean(dim=-2), inference.py:267
+                // chars.mean(dim=-2), inference.py:267: four independent LDS reads per step (two accumulators keep the adds off one chain)
+                vec_t acc0 = (vec_t)(0.f), acc1 = (vec_t)(0.f);
+                int k = 0;
+                for (; k + 4 <= A.bpt; k += 4) {
+                    const int i0 = __shfl(idv[u], k, 64), i1 = __shfl(idv[u], k + 1, 64), i2 = __shfl(idv[u], k + 2, 64), i3 = __shfl(idv[u], k + 3, 64);
+                    vec_t v0 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i0 * slice_cols + c));
+                    vec_t v1 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i1 * slice_cols + c));
+                    vec_t v2 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i2 * slice_cols + c));
+                    vec_t v3 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i3 * slice_cols + c));
+                    if (A.norm_byte) { v0 *= A.byte_rnorm[i0]; v1 *= A.byte_rnorm[i1]; v2 *= A.byte_rnorm[i2]; v3 *= A.byte_rnorm[i3]; }
+                    acc0 += v0; acc1 += v1; acc0 += v2; acc1 += v3;
+                }
+                for (; k < A.bpt; ++k) {
                     const int id = __shfl(idv[u], k, 64);
                     vec_t v = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)id * slice_cols + c));
                     if (A.norm_byte) v *= A.byte_rnorm[id];
-                    acc += v;
+                    acc0 += v;
                 }
+                const vec_t acc = acc0 + acc1;
                 vec_t a = Elem<T>::widen(ar[u]);
                 if (A.scale_tok) a *= s_tok;
                 const vec_t b = acc * inv_bpt;                // exact for the power-of-two slot counts of the reference (8), else within an ulp of acc / bpt
                 const vec_t x = a + (A.scale_byte ? b * s_byte : b);
-                Elem<T>::storev_nt(out + n * D + col0 + c, x);
+                if (n < n1) Elem<T>::storev_nt(out + n * D + col0 + c, x);
             }
         }
     }
