@@ -1003,7 +1003,7 @@ static int launch_widen(const void *src, size_t n, float *dst, hipStream_t strea
 // du = dy . W of the bf16 backward on the bf16 MFMA (what autograd does for bf16 parameters): dy rounded to bf16,
 // W^T as the [K, Dm] "weight" of the forward bf16 kernel in dense-row mode, du widened back for the scatter stage.
 // Scratch behind the fp32 layouts, in bytes: [dy16: N*Dm*2][wt16: K*Dm*2][du16: N*K*2][byte0: 16][kernel workspace].
-struct Du16Layout { size_t dy16, wt16, du16, byte0, lin, lin_bytes, total; };
+struct Du16Layout { size_t dy16, wt16, du16, byte0, dyT, uT, lin, lin_bytes, total; };
 static void du16_desc(MotEmbedMixDesc &g, const MotEmbedMixDesc &d, int64_t N, int K) {
     memset(&g, 0, sizeof(g));
     g.struct_size = sizeof(g); g.dtype = MOT_BF16;
@@ -1018,6 +1018,7 @@ static Du16Layout du16_layout(const MotEmbedMixDesc &d) {
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     U.dy16 = take(N * Dm * 2); U.wt16 = take(K * Dm * 2); U.du16 = take(N * K * 2); U.byte0 = take(16);
+    U.dyT = take(N * Dm * 2); U.uT = take(N * K * 2);   // token-major -> token-minor copies for the dW GEMM
     MotEmbedMixDesc g;
     du16_desc(g, d, (int64_t)N, (int)K);
     U.lin_bytes = embed_mix_linear_bf16_workspace_bytes(g);
@@ -1027,7 +1028,8 @@ static Du16Layout du16_layout(const MotEmbedMixDesc &d) {
 }
 static bool du16_usable(const MotEmbedMixDesc &d) {
     const int K = d.tok_dim + d.bpt * d.byte_dim;
-    return d.dtype == MOT_BF16 && (d.model_dim & 7) == 0 && (K & 7) == 0 && K <= 1024 && !getenv("MOT_NO_DU16");
+    return d.dtype == MOT_BF16 && (d.model_dim & 7) == 0 && (K & 7) == 0 && K <= 1024 && ((d.n_rows * d.tokens_per_row) & 7) == 0 &&
+           !getenv("MOT_NO_DU16");
 }
 
 __global__ __launch_bounds__(kThreads) void narrow_kernel(const float *__restrict__ src, int64_t n, __bf16 *__restrict__ dst) {
@@ -1041,6 +1043,106 @@ __global__ __launch_bounds__(kThreads) void narrow_kernel(const float *__restric
             for (int64_t j = i; j < n; ++j) dst[j] = (__bf16)src[j];
         }
     }
+}
+
+// dst[c][r] = bf16(src[r][c])  (fp32 rows x cols -> bf16 cols x rows): the token-minor operands of the dW GEMM
+__global__ __launch_bounds__(kThreads) void narrow_transpose_kernel(const float *__restrict__ src, int64_t rows, int cols, int ld, __bf16 *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(r0 + r) * ld + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < cols && r0 + tx < rows) dst[(int64_t)(c0 + c) * rows + r0 + tx] = (__bf16)tile[tx][c];
+}
+
+// C[m][n] += sum_k A[m][k] * B[n][k]   (A: M x Kc, B: Nn x Kc, both bf16 with k contiguous; C fp32, leading dimension ldc)
+// on v_mfma_f32_32x32x16_bf16, split over k: blockIdx.z takes k in [z*kper, (z+1)*kper) and adds its partial tile with
+// float atomics (128-byte contiguous segments).  Workgroup tile 128 x 128, 4 waves as 2 x 2, each 64 x 64; K step 32,
+// LDS rows of 64 data + 16 pad bytes, double buffered.  Used for dW = dy^T u with k = the token index.
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(kThreads) void gemm_nt_bf16_splitk_kernel(const __bf16 *__restrict__ A_, int M, const __bf16 *__restrict__ B_, int Nn, int64_t Kc,
+                                                                       int64_t kper, float *__restrict__ C, int ldc) {
+    constexpr int RB = 80;   // bytes per staged row
+    __shared__ __attribute__((aligned(16))) char lA[2][128 * RB], lB[2][128 * RB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
+    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
+    const int64_t k_lo = (int64_t)blockIdx.z * kper, k_hi = min(Kc, k_lo + kper);
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // staging: 128 rows x 4 pieces of 16 bytes per operand = 512 pieces -> 2 per thread
+    bf16x8w ra[2], rb[2];
+    auto load_stage = [&](int64_t k) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + tid, row = q >> 2, c = q & 3;
+            const int64_t kk = k + 8 * c;
+            ra[p] = (bf16x8w)((__bf16)0.f); rb[p] = (bf16x8w)((__bf16)0.f);
+            if (kk < k_hi) {   // Kc and the k split are multiples of 8: a piece is wholly inside or outside
+                if (m0 + row < M) ra[p] = *(const bf16x8w *)(A_ + (int64_t)(m0 + row) * Kc + kk);
+                if (n0 + row < Nn) rb[p] = *(const bf16x8w *)(B_ + (int64_t)(n0 + row) * Kc + kk);
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + tid, row = q >> 2, c = q & 3;
+            *(bf16x8w *)(&lA[buf][row * RB + 16 * c]) = ra[p];
+            *(bf16x8w *)(&lB[buf][row * RB + 16 * c]) = rb[p];
+        }
+    };
+    load_stage(k_lo);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t k = k_lo; k < k_hi; k += 32, buf ^= 1) {
+        const bool more = k + 32 < k_hi;
+        if (more) load_stage(k + 32);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8w af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) af[a] = *(const bf16x8w *)(&lA[buf][(wm + a * 32 + li) * RB + 32 * ks + 16 * h]);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) bf[b] = *(const bf16x8w *)(&lB[buf][(wn + b * 32 + li) * RB + 32 * ks + 16 * h]);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i][j]: lane -> j (B row = output column n), registers -> i (A row = output row m)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + b * 32 + li;
+                if (m < M && n < Nn) atomicAdd(C + (int64_t)m * ldc + n, acc[a][b][r]);
+            }
+}
+
+static int launch_gemm_nt_bf16(const __bf16 *A_, int M, const __bf16 *B_, int Nn, int64_t Kc, float *C, int ldc, hipStream_t stream) {
+    if (M <= 0 || Nn <= 0 || Kc <= 0) return MOT_OK;
+    const int gx = (M + 127) / 128, gy = (Nn + 127) / 128;
+    int64_t splits = (1024 + gx * gy - 1) / (gx * gy);
+    int64_t kper = ((Kc + splits - 1) / splits + 31) / 32 * 32;
+    if (kper < 512) kper = 512;
+    splits = (Kc + kper - 1) / kper;
+    hipLaunchKernelGGL(gemm_nt_bf16_splitk_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits), dim3(kThreads), 0, stream, A_, M, B_, Nn, Kc, kper, C, ldc);
+    return check_launch("gemm_nt_bf16_splitk_kernel");
 }
 
 // dst[c][r] = src[r][c]   (rows x cols -> cols x rows), bf16, 32 x 32 tiles through LDS
@@ -1130,8 +1232,21 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
                                  MOT_F32, stream))) return rc;
     const int tok_lo = d.bytes_first ? nbk : 0, byte_lo = d.bytes_first ? 0 : Dt;
     float *dW = (float *)gr.d_weight;
-    if ((rc = launch_gemm_tn(dyp, Dm, Dm, utok, Dt, Dt, N, dW + tok_lo, K, stream))) return rc;
-    if ((rc = launch_gemm_tn(dyp, Dm, Dm, ubyte, nbk, nbk, N, dW + byte_lo, K, stream))) return rc;
+    if (w16) {
+        // 2'. dW on the bf16 MFMA: token-minor bf16 copies of dy and of the two parts of u, contraction over the tokens
+        const Du16Layout U = du16_layout(d);
+        __bf16 *dyT = (__bf16 *)(ws16 + U.dyT), *uT = (__bf16 *)(ws16 + U.uT);
+        const unsigned gxN = (unsigned)((N + 31) / 32);
+        hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream, dyp, N, Dm, Dm, dyT);
+        hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((Dt + 31) / 32)), dim3(kThreads), 0, stream, utok, N, Dt, Dt, uT);
+        hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((nbk + 31) / 32)), dim3(kThreads), 0, stream, ubyte, N, nbk, nbk, uT + (size_t)Dt * N);
+        if ((rc = check_launch("narrow_transpose_kernel"))) return rc;
+        if ((rc = launch_gemm_nt_bf16(dyT, Dm, uT, Dt, N, dW + tok_lo, K, stream))) return rc;
+        if ((rc = launch_gemm_nt_bf16(dyT, Dm, uT + (size_t)Dt * N, nbk, N, dW + byte_lo, K, stream))) return rc;
+    } else {
+        if ((rc = launch_gemm_tn(dyp, Dm, Dm, utok, Dt, Dt, N, dW + tok_lo, K, stream))) return rc;
+        if ((rc = launch_gemm_tn(dyp, Dm, Dm, ubyte, nbk, nbk, N, dW + byte_lo, K, stream))) return rc;
+    }
     hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(kThreads), 0, stream, iota, N);
     if (w16) {
         // 3'. du on the bf16 MFMA: bf16(dy) rows x W^T, through the forward bf16 kernel in dense-row mode, widened for step 4
