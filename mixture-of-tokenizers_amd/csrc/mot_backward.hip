@@ -832,6 +832,35 @@ __global__ __launch_bounds__(kThreads) void dy_kernel(const float *__restrict__ 
     for (int j = lane; j < Dm; j += 64) dy[r * Dm + j] = ry * (gr[j] - xr[j] * m);
 }
 
+// the same from bf16 g and x, result in bf16 (the bf16 route never needs an fp32 dy): Dm a multiple of 8, <= 4096
+__global__ __launch_bounds__(kThreads) void dy16_kernel(const __bf16 *__restrict__ g, const __bf16 *__restrict__ x, const float *__restrict__ rnorm, int64_t n,
+                                                        int Dm, __bf16 *__restrict__ dy) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const __bf16 *gr = g + r * Dm, *xr = x + r * Dm;
+    float8v gv[8], xv[8];
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = 8 * (lane + 64 * i);
+        gv[i] = (float8v)(0.f); xv[i] = (float8v)(0.f);
+        if (c < Dm) {
+            gv[i] = Elem<__bf16>::loadv(gr + c);
+            xv[i] = Elem<__bf16>::loadv(xr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m += gv[i][e] * xv[i][e];
+        }
+    }
+    m = wave_sum(m) / (float)Dm;
+    const float ry = rnorm[r];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = 8 * (lane + 64 * i);
+        if (c < Dm) Elem<__bf16>::storev_nt(dy + r * Dm + c, (gv[i] - xv[i] * m) * ry);
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void colsum_kernel(const float *__restrict__ a, int64_t n, int cols, float *__restrict__ out) {
     // each workgroup sums a strip of rows for every column, then one atomic per column
     const int64_t rows_per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * rows_per, hi = min(n, lo + rows_per);
@@ -1166,9 +1195,11 @@ size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
     return (bwd_rnorm_floats(d) + scatter_ws_ints(d)) * 4;
 }
 
-// `w16` / `ws16` (optional): the bf16 weight and the Du16Layout scratch -- then du runs on the bf16 MFMA
+// `w16` / `ws16` (optional): the bf16 weight and the Du16Layout scratch -- then du and dW run on the bf16 MFMA; `g16` / `x16`
+// (optional with them): the bf16 upstream gradient and forward output -- then dy is produced in bf16 directly and
+// gr.grad_out / d.out (fp32) are never read
 static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream, const void *w16 = nullptr,
-                                       char *ws16 = nullptr) {
+                                       char *ws16 = nullptr, const void *g16 = nullptr, const void *x16 = nullptr) {
     if (d.id_source != MOT_IDS_GIVEN) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
     if (!gr.d_weight) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: d_weight missing");
     if (d.norm_out && (!d.out || !d.out_row_rnorm)) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: needs the forward's out and out_row_rnorm");
@@ -1187,8 +1218,12 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         if ((rc = launch_widen(d.byte_table, (size_t)d.byte_rows * d.byte_dim, up + U.byte, stream))) return rc;
         if ((rc = launch_widen(d.weight, (size_t)Dm * K, up + U.w, stream))) return rc;
         if (d.bias && (rc = launch_widen(d.bias, Dm, up + U.bias, stream))) return rc;
-        if ((rc = launch_widen(gr.grad_out, Nn, up + U.g, stream))) return rc;
-        if (d.norm_out && (rc = launch_widen(d.out, Nn, up + U.x, stream))) return rc;
+        const bool route16 = du16_usable(d);
+        const bool dy_in_bf16 = route16 && !d.bias && Dm <= 4096;   // the bias gradient is a column sum of an fp32 dy
+        if (!dy_in_bf16) {
+            if ((rc = launch_widen(gr.grad_out, Nn, up + U.g, stream))) return rc;
+            if (d.norm_out && (rc = launch_widen(d.out, Nn, up + U.x, stream))) return rc;
+        }
         MotEmbedMixDesc d32 = d;
         MotEmbedMixGrads g32 = gr;
         d32.dtype = MOT_F32;
@@ -1197,11 +1232,12 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         d32.eps = d.eps > 0.f ? d.eps : kBf16Eps;   // the forward normalised with the bf16 epsilon
         d32.workspace = up + U.total; d32.workspace_bytes = d.workspace_bytes - U.total * 4;
         g32.grad_out = up + U.g;
-        if (du16_usable(d)) {
+        if (route16) {
             const size_t off = ((U.total + L.total) * 4 + 255) & ~(size_t)255;
             if (d.workspace_bytes < off + du16_layout(d).total)
                 return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", off + du16_layout(d).total, d.workspace_bytes);
-            return launch_embed_mix_bwd_linear(d32, g32, stream, d.weight, (char *)d.workspace + off);
+            return launch_embed_mix_bwd_linear(d32, g32, stream, d.weight, (char *)d.workspace + off, dy_in_bf16 ? gr.grad_out : nullptr,
+                                               dy_in_bf16 ? d.out : nullptr);
         }
         return launch_embed_mix_bwd_linear(d32, g32, stream);
     }
@@ -1214,7 +1250,19 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     int rc;
     // 1. dy
     const float *dyp = (const float *)gr.grad_out;
-    if (d.norm_out) {
+    const __bf16 *dy16p = nullptr;   // bf16 route with bf16 inputs: dy exists in bf16 only
+    if (g16) {
+        const Du16Layout U = du16_layout(d);
+        dy16p = (const __bf16 *)g16;
+        if (d.norm_out) {
+            __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16);
+            hipLaunchKernelGGL(dy16_kernel, dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const __bf16 *)g16, (const __bf16 *)x16,
+                               d.out_row_rnorm, N, Dm, dy16);
+            if ((rc = check_launch("dy16_kernel"))) return rc;
+            dy16p = dy16;
+        }
+        dyp = nullptr;
+    } else if (d.norm_out) {
         hipLaunchKernelGGL(dy_kernel, dim3((unsigned)((N + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)gr.grad_out,
                            (const float *)d.out, d.out_row_rnorm, N, Dm, dy);
         if ((rc = check_launch("dy_kernel"))) return rc;
@@ -1237,7 +1285,10 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         const Du16Layout U = du16_layout(d);
         __bf16 *dyT = (__bf16 *)(ws16 + U.dyT), *uT = (__bf16 *)(ws16 + U.uT);
         const unsigned gxN = (unsigned)((N + 31) / 32);
-        hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream, dyp, N, Dm, Dm, dyT);
+        if (dy16p)
+            hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((Dm + 31) / 32), gxN), dim3(kThreads), 0, stream, dy16p, (int)N, Dm, dyT);
+        else
+            hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream, dyp, N, Dm, Dm, dyT);
         hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((Dt + 31) / 32)), dim3(kThreads), 0, stream, utok, N, Dt, Dt, uT);
         hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((nbk + 31) / 32)), dim3(kThreads), 0, stream, ubyte, N, nbk, nbk, uT + (size_t)Dt * N);
         if ((rc = check_launch("narrow_transpose_kernel"))) return rc;
@@ -1254,7 +1305,8 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16), *wt16 = (__bf16 *)(ws16 + U.wt16), *du16 = (__bf16 *)(ws16 + U.du16);
         size_t nb = ((size_t)N * Dm / 8 + kThreads) / kThreads;
         if (nb > 4096) nb = 4096;
-        hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dyp, (int64_t)N * Dm, dy16);
+        if (dy16p) dy16 = const_cast<__bf16 *>(dy16p);
+        else hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dyp, (int64_t)N * Dm, dy16);
         hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream,
                            (const __bf16 *)w16, Dm, K, wt16);
         hipError_t e16 = hipMemsetAsync(ws16 + U.byte0, 0, 16, stream);

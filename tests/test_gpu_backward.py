@@ -236,7 +236,7 @@ def test_grad_bucket_accumulates_in_place(mot):
     assert all(float(p.grad.abs().max()) == 0.0 for p in bucket.params)
     (fe(dev(toks)) * dev(g)).sum().backward()
     for a, p in zip(acc, bucket.params):
-        assert rel(host(a), host(p.grad)) < TOL
+        assert rel(host(a), host(p.grad)) < 2 * TOL          # two GPU results, each within TOL of the exact gradient
 
 
 def test_sum_backward_many_chunks(mot):
