@@ -212,6 +212,8 @@ def test_bf16_sum_backward_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
     (256, 32, 16, 768, 4096, 2, 512, dict(norm_tok=True, norm_byte=True, norm_out=True), 9801),     # C2-CONCAT dims
     (256, 256, 3, 256, 1003, 8, 32, dict(bias=True, bytes_first=True), 9802),                       # mathblations dims
     (256, 48, 16, 1024, 2048, 2, 160, dict(norm_tok=True, norm_byte=True, norm_out=True, dual=True), 9803),
+    (64, 16, 8, 128, 512, 1, 77, dict(norm_tok=True, norm_out=True), 9804),      # token count not a multiple of 8: the fp32-MFMA backward route
+    (64, 16, 8, 128, 512, 3, 40, dict(norm_byte=True), 9805),                    # no post-norm: dy is the upstream gradient itself
 ])
 def test_bf16_concat_backward_through_autograd(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     kw = dict(kw)
