@@ -477,7 +477,7 @@ def gen_grads(dc, tg, r71, mmodel):
 
 
 # ------------------------------------------------------------------ bf16 (the dtype the training loop runs)
-def gen_bf16(dc, tg, r71):
+def gen_bf16(dc, tg, r71):  # noqa: C901
     """The same modules with bf16 tables, eager on CPU (train_gpt.py:1124-1126 casts nn.Embedding to bf16;
     runs/7*.py do the same).  Outputs are bf16, stored widened to float32 (exact)."""
     out = {}
@@ -496,6 +496,28 @@ def gen_bf16(dc, tg, r71):
         out["sum/r71041"] = t2n(mixin_bytes(norm(et[tok1d][None]) * sc[-1], norm(eb[byte_inputs].squeeze()) * sc[-2]).float())
         out["sum/noop"] = t2n(norm(et[tok1d][None]).float())
         out["sum/byte_embs"] = t2n(norm(eb[pulled.view(-1)]).float())
+    # concat mixin in the production dtypes: bf16 nn.Embedding tables (train_gpt.py:1124-1126), fp32 CastedLinear master weight
+    # cast to the activations' dtype per call (185-186), eager on CPU.  x is bf16, stored widened (exact).
+    for (cname, Vt2, Dt2, Db2, Dm2, bpt2, B2, T2, seed2) in SCALED_CASES[:1] + [("c2row", 512, 256, 32, 768, 16, 1, 40, 403)]:
+        tab2 = gi.synth_ttb(seed2 + 1000, Vt2, bpt2, "left")
+        toks2 = gi.edge_tokens(seed2, B2, T2, Vt2, eot_p=0.08)
+        padded2 = dc.tokens_to_bytes(torch.from_numpy(toks2), ttb_embedding(tab2))
+        pulled2 = dc.pull_from_left(padded2, bpt2, gi.PAD, gi.EOT)
+        bp = tg["ByteHyperparameters"](bytes_per_token=bpt2, vocab_size=gi.BYTE_VOCAB, byte_mixin_method="concat", pull_in=True)
+        dims = tg["ModelDims"](model_dim=Dm2, byte_dim=Db2, token_dim=Dt2)
+        emb, mix = tg["FlexibleEmbedding"](dims, Vt2, bp), tg["ByteMixin"](dims, T2, bp)
+        emb.embed_tokens.weight.data = torch.from_numpy(gi.normal_table(seed2 + 1, Vt2, Dt2))
+        emb.embed_bytes.weight.data = torch.from_numpy(gi.normal_table(seed2 + 2, gi.BYTE_VOCAB, Db2))
+        mix.mixin.mixin.weight.data = torch.from_numpy(gi.casted_linear_weight(seed2 + 3, Dm2, Dt2 + bpt2 * Db2)).float()
+        for m in emb.modules():
+            if isinstance(m, torch.nn.Embedding):
+                m.bfloat16()
+        with torch.no_grad():
+            xt, xb = emb(tokens=torch.from_numpy(toks2), byte_tensor=padded2, byte_tensor_pulled=pulled2)
+            x = mix(xt, xb)
+        assert x.dtype == torch.bfloat16
+        out[f"concat/{cname}/tokens"], out[f"concat/{cname}/pulled"] = toks2, t2n(pulled2)
+        out[f"concat/{cname}/x"] = t2n(x.float())
     np.savez_compressed(OUT / "bf16.npz", **out)
     print("bf16:", len(out), "arrays")
 
@@ -582,6 +604,9 @@ def gen_cross_attn_grads(dc, tg):
 def main():
     if sys.argv[1:] == ["cross_attn"]:          # regenerate one fixture without touching the others
         gen_cross_attn(load_data_creation(), load_train_gpt_defs())
+        return
+    if sys.argv[1:] == ["bf16"]:
+        gen_bf16(load_data_creation(), load_train_gpt_defs(), load_run71_defs())
         return
     dc = load_data_creation()
     gen_ttb_fixture()
