@@ -390,10 +390,90 @@ class DigitMixinNoOp(nn.Module):  # model.py:271-276
         return x
 
 
+class DigitRotary(nn.Module):  # model.py:32-49
+    """cos/sin tables of mathblations' Rotary: built on the host with the reference's expressions (its inv_freq is a plain
+    CPU attribute, so the reference computes them there too), rounded to bfloat16 (lines 47-48) and handed to the kernel
+    as fp32 -- the product of an fp32 head with a bf16 table promotes to fp32 in apply_rotary_emb (51-58)."""
+
+    def __init__(self, dim: int, base=10000):
+        super().__init__()
+        self.inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2).float() / dim))
+        self._cached: dict = {}
+
+    def tables(self, seq_len: int, rows: int, device) -> tuple[Tensor, Tensor]:
+        """(cos, sin), each (rows * seq_len, dim / 2): the positions 0..seq_len-1 once per batch row."""
+        key = (seq_len, rows, str(device))
+        if key not in self._cached:
+            t = torch.arange(seq_len).type_as(self.inv_freq)
+            freqs = torch.outer(t, self.inv_freq)
+            if len(self._cached) >= 8:   # q and k lengths of a few batch shapes; the reference caches one length
+                self._cached.clear()
+            self._cached[key] = tuple(f.bfloat16().float().repeat(rows, 1).contiguous().to(device) for f in (freqs.cos(), freqs.sin()))
+        return self._cached[key]
+
+
+class DigitCrossAttention(nn.Module):
+    """mathblations/model.py:89-154 with k_gt_q (the mixin side): token t attends to its own ``length_factor`` digit
+    embeddings (block mask ``q_idx == kv_idx // length_factor``, line 111).  Same parameters (c_q, c_k, c_v, c_proj:
+    nn.Linear without bias) under the same names; forward takes the two embedding handles so that the gathers, input
+    norms, projections, per-head norm, RoPE and the softmax run in libmot_hip.so.  head_dim 128 (n_embd / n_head of
+    every run in ablations-mixin.sh and of the GPTConfig defaults)."""
+
+    def __init__(self, config: GPTConfig):
+        super().__init__()
+        self.config = config
+        self.n_head, self.n_embd = config.n_head, config.n_embd_tok
+        assert self.n_embd % self.n_head == 0
+        self.head_dim = self.n_embd // self.n_head
+        self.length_factor = config.length_factor
+        if not config.k_gt_q:
+            raise NotImplementedError("CrossAttention with k_gt_q=False is the output side (DigitMixoutCrossAttention, model.py:213-228)")
+        if self.head_dim != 128:
+            raise NotImplementedError("DigitCrossAttention: head_dim 128 only (n_embd_tok / n_head)")
+        self.c_q = nn.Linear(self.n_embd, self.n_embd, bias=False)
+        self.c_k = nn.Linear(self.n_embd, self.n_embd, bias=False)
+        self.c_v = nn.Linear(self.n_embd, self.n_embd, bias=False)
+        self.c_proj = nn.Linear(self.n_embd, self.n_embd, bias=False)
+        self.rotary = DigitRotary(self.head_dim)
+
+    def forward(self, x_q, x_kv) -> Tensor:
+        if not (isinstance(x_q, EmbedHandle) and isinstance(x_kv, EmbedHandle)):
+            raise NotImplementedError("DigitCrossAttention: pass the handles of LazyEmbedding wte / dte (materialised inputs are not built)")
+        tokens, digits = x_q.tokens, x_kv.ids_a
+        if tokens.ndim == 1:
+            tokens, digits = tokens[None], digits[None]
+        B, T = tokens.shape
+        lf = self.length_factor
+        assert digits.shape[0] == B, f"Batch sizes must match: {B} vs {digits.shape[0]}"                       # model.py:129
+        assert digits.shape[1] == T * lf, f"KV length {digits.shape[1]} must be {lf}x Q length {T}"             # model.py:132
+        dev = tokens.device
+        (cos_q, sin_q), (cos_k, sin_k) = self.rotary.tables(T, B, dev), self.rotary.tables(T * lf, B, dev)
+        one = torch.ones((), dtype=torch.float32, device=dev)
+        # rows of the batch laid end to end: a token only ever sees its own digits and the rotary tables repeat per row
+        x = F_mot.cross_attn(tokens.reshape(1, B * T), digits.reshape(1, B * T * lf), _f32(x_q.tok_weight, "token table"),
+                             _f32(x_kv.byte_weight, "digit table"), q_w=self.c_q.weight, kv_w=torch.stack([self.c_k.weight, self.c_v.weight]),
+                             proj_w=self.c_proj.weight, lambda_factor=one, cos_q=cos_q, sin_q=sin_q, cos_k=cos_k, sin_k=sin_k,
+                             bpt=lf, n_heads=self.n_head, norm_tok=True, norm_byte=True, head_layout="per_token")
+        return x.view(B, T, self.n_embd)
+
+
+class DigitMixinCrossAttention(nn.Module):  # model.py:239-253
+    def __init__(self, config: GPTConfig):
+        assert config.n_embd_digit == config.n_embd_tok
+        super().__init__()
+        self.config = config
+        if config.use_digit_self_attn:
+            raise NotImplementedError("use_digit_self_attn (model.py:244,248-249) is outside the front-end path")
+        self.digit_attn = nn.Identity()
+        self.cross_attn = DigitCrossAttention(config)
+
+    def forward(self, we, de) -> Tensor:
+        # F.rms_norm of both inputs (model.py:250-253) happens inside the launch
+        return self.cross_attn(x_q=we, x_kv=de)
+
+
 def make_digit_mixin(config: GPTConfig):  # model.py:279-284
-    if config.digit_mixin_method == "cross_attn":
-        raise NotImplementedError("digit_mixin_method='cross_attn' (model.py:239-253) is a later scope row")
-    return {"noop": DigitMixinNoOp, "concat": DigitMixinConcat}[config.digit_mixin_method](config)
+    return {"noop": DigitMixinNoOp, "cross_attn": DigitMixinCrossAttention, "concat": DigitMixinConcat}[config.digit_mixin_method](config)
 
 
 class DigitFrontEnd(nn.Module):

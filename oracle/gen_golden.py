@@ -601,9 +601,68 @@ def gen_cross_attn_grads(dc, tg):
     print("cross_attn_grads:", len(out), "arrays")
 
 
+def gen_digit_cross_attn(mmodel, mdata):
+    """mathblations DigitMixinCrossAttention (model.py:239-253 -> CrossAttention 89-154), use_digit_self_attn=False:
+    forward in fp32 / float64 and the float64 autograd gradients.  CrossAttention.__init__ builds its block mask with
+    create_block_mask's default device ("cuda", model.py:119-121), which does not exist on this host: the name is rebound
+    to the same torch function with device="cpu" for the construction; flex_attention then runs its eager CPU path."""
+    import functools
+    from torch import nn
+    mmodel.create_block_mask = functools.partial(mmodel.create_block_mask, device="cpu")
+    out = {}
+    for (name, mdpt, mtpn, D, H, B, seed) in gi.DIGIT_CROSS_CASES:
+        random.seed(seed)
+        gen = mdata.GenerateEquations(max_digits_per_token=mdpt, max_tokens_per_num=mtpn)
+        xs, xd = [], []
+        for _ in range(B):
+            x_tokens, x_digit_tokens, *_ = gen()
+            xs.append(x_tokens); xd.append(x_digit_tokens)
+        x_tokens, x_digits = torch.stack(xs), torch.stack(xd)
+        T = x_tokens.shape[1]
+        assert x_digits.shape == (B, T * mdpt) and T == gen.max_possible_num_tokens - 1
+        out[f"{name}/x_tokens"], out[f"{name}/x_digit_tokens"] = t2n(x_tokens), t2n(x_digits)
+        Wt, Wd = gi.normal_table(seed + 1, gen.vocab_size, D), gi.normal_table(seed + 2, 14, D)
+        ws = gi.digit_cross_weights(seed + 3, D)
+        g = np.random.RandomState(seed + 9).standard_normal((B, T, D)).astype(np.float32)
+        out[f"{name}/g"] = g
+        for dt_name, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+            cfg = mmodel.GPTConfig(vocab_size=gen.vocab_size, n_layer=1, n_head=H, n_embd_tok=D, n_embd_digit=D, T=T + 1,
+                                   length_factor=mdpt, digit_mixin_method="cross_attn", digit_mixout_method="noop")
+            wte, dte = nn.Embedding(gen.vocab_size, D).to(tdt), nn.Embedding(14, D).to(tdt)   # model.py:304-305
+            mix = mmodel.make_digit_mixin(cfg).to(tdt)
+            assert sorted(dict(mix.state_dict())) == ["cross_attn.c_k.weight", "cross_attn.c_proj.weight", "cross_attn.c_q.weight",
+                                                      "cross_attn.c_v.weight"]
+            wte.weight.data, dte.weight.data = torch.from_numpy(Wt).to(tdt), torch.from_numpy(Wd).to(tdt)
+            ca = mix.cross_attn
+            for lin, w in zip((ca.c_q, ca.c_k, ca.c_v, ca.c_proj), ws):
+                lin.weight.data = torch.from_numpy(w).to(tdt)
+            we, de = wte(x_tokens), dte(x_digits)          # model.py:323, 326
+            x = mix(we, de)                                # model.py:327
+            assert x.shape == (B, T, D) and x.dtype == tdt
+            out[f"{name}/{dt_name}/x"] = t2n(x)
+            if dt_name == "f32":   # the Rotary module's cached tables after the call (model.py:40-49): bf16 values
+                (cq, sq), (ck, sk) = ca.rotary(torch.empty(1, T, 1, 1)), ca.rotary(torch.empty(1, T * mdpt, 1, 1))
+                out[f"{name}/cos_q"], out[f"{name}/sin_q"] = t2n(cq[0, :, 0].float()), t2n(sq[0, :, 0].float())
+                out[f"{name}/cos_k"], out[f"{name}/sin_k"] = t2n(ck[0, :, 0].float()), t2n(sk[0, :, 0].float())
+                continue
+            (x * torch.from_numpy(g).double()).sum().backward()
+            for key, p_ in (("d_tok", wte.weight), ("d_digit", dte.weight)):
+                gr = t2n(p_.grad)
+                rows = np.flatnonzero(np.abs(gr).sum(1))
+                out[f"{name}/{key}_rows"] = rows.astype(np.int32)
+                out[f"{name}/{key}_vals"] = gr[rows].astype(np.float32)
+            for key, lin in (("d_cq", ca.c_q), ("d_ck", ca.c_k), ("d_cv", ca.c_v), ("d_cproj", ca.c_proj)):
+                out[f"{name}/{key}"] = t2n(lin.weight.grad).astype(np.float32)
+    np.savez_compressed(OUT / "digit_cross_attn.npz", **out)
+    print("digit_cross_attn:", len(out), "arrays")
+
+
 def main():
     if sys.argv[1:] == ["cross_attn"]:          # regenerate one fixture without touching the others
         gen_cross_attn(load_data_creation(), load_train_gpt_defs())
+        return
+    if sys.argv[1:] == ["digit_cross_attn"]:
+        gen_digit_cross_attn(*load_mathblations())
         return
     if sys.argv[1:] == ["bf16"]:
         gen_bf16(load_data_creation(), load_train_gpt_defs(), load_run71_defs())
@@ -620,6 +679,7 @@ def main():
     gen_grads(dc, load_train_gpt_defs(), load_run71_defs(), mm[0])
     gen_bf16(dc, load_train_gpt_defs(), load_run71_defs())
     gen_cross_attn(dc, load_train_gpt_defs())
+    gen_digit_cross_attn(*mm)
     meta = dict(torch=torch.__version__, numpy=np.__version__, python=sys.version.split()[0],
                 threads=torch.get_num_threads(), reference="snimu/mixture-of-tokenizers @ 2025-08-24",
                 generator="oracle/gen_golden.py")

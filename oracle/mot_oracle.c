@@ -267,6 +267,10 @@ void oracle_set_eps(double eps) { g_eps_override = eps; }
  * when they enter F.linear, so the concat operand is rounded to bf16 (nearest-even) element by element. */
 static int g_round_seg_bf16 = 0;
 void oracle_set_round_segments_bf16(int on) { g_round_seg_bf16 = on; }
+/* Rotary: scaled-pre-train casts the head to float32 first (train_gpt.py:202); mathblations' apply_rotary_emb
+ * (model.py:51-58) keeps the head's dtype.  Only the float64 instantiation can tell the two apart. */
+static int g_rotary_f32_cast = 1;
+void oracle_set_rotary_f32_cast(int on) { g_rotary_f32_cast = on; }
 static double bf16_rne(double x) {
     float f = (float)x; uint32_t u; memcpy(&u, &f, 4);
     u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;

@@ -61,6 +61,12 @@ def set_round_segments_bf16(on: bool) -> None:
     lib().oracle_set_round_segments_bf16(C.c_int(int(on)))
 
 
+def set_rotary_f32_cast(on: bool) -> None:
+    """Rotary casts each head to float32 before rotating (train_gpt.py:202, the default) or keeps its dtype
+    (mathblations/model.py:51-58); a difference in the float64 functions only."""
+    lib().oracle_set_rotary_f32_cast(C.c_int(int(on)))
+
+
 def bf16_round(a) -> np.ndarray:
     """Round float32/float64 values to the nearest bfloat16 (ties to even), returned as float32."""
     x = np.ascontiguousarray(a, dtype=np.float32)

@@ -186,6 +186,21 @@ def cross_weights(seed, D):
     return q_w, kv_w, casted_linear_weight(seed + 1, D, D)
 
 
+def digit_cross_weights(seed, D):
+    """c_q, c_k, c_v, c_proj weights (D, D) ~ U(+-1/sqrt(D)), the nn.Linear default that mathblations' CrossAttention
+    keeps (model.py:101-105)."""
+    rs = np.random.RandomState(seed)
+    bound = D ** -0.5
+    return tuple(rs.uniform(-bound, bound, (D, D)).astype(np.float32) for _ in range(4))
+
+
+DIGIT_CROSS_CASES = [
+    # name, max_digits_per_token (= length_factor), max_tokens_per_num, D, heads, B, seed
+    ("c1", 3, 10, 256, 2, 8, 811),      # config 1: GenerateEquations defaults, 8 x 32 tokens, 1003-token vocabulary
+    ("runcfg", 4, 3, 256, 2, 8, 812),   # ablations-mixin.sh:2: 4 digits per token, 8 x 11 tokens, 10003-token vocabulary
+]
+
+
 CROSS_CASES = [
     # name, Vt, D (= token = byte = model dim; heads = D/128), bpt, T, seed
     ("h1", 97, 128, 4, 12, 701),        # one head: the .view() of train_gpt.py:283-284 is the identity permutation

@@ -227,3 +227,78 @@ def test_cross_attn_kv_table_cache(mot):
         ca.lambda_factor.fill_(0.9)
         d = mixin(*embed(**args))
         assert not torch.equal(c, d)
+
+
+# ------------------------------------------------------------------------------------------------
+# mathblations: DigitMixinCrossAttention (model.py:239-253 -> 89-154) through wte / dte / digit_mixin of DigitFrontEnd,
+# against what the reference modules produced (tests/golden/digit_cross_attn.npz).  Same bars as above.
+# ------------------------------------------------------------------------------------------------
+def build_digit(case):
+    from mixture_of_tokenizers_amd import modules as M
+    name, lf, mtpn, D, H, B, seed = case
+    z = np.load(G / "digit_cross_attn.npz")
+    Vt = 10 ** lf + 3
+    T = z[f"{name}/x_tokens"].shape[1]
+    cfg = M.GPTConfig(vocab_size=Vt, n_layer=1, n_head=H, n_embd_tok=D, n_embd_digit=D, T=T + 1, length_factor=lf,
+                      digit_mixin_method="cross_attn")
+    net = M.DigitFrontEnd(cfg).to(DEV)
+    ca = net.digit_mixin.cross_attn
+    with torch.no_grad():
+        net.wte.weight.copy_(dev(f32(gi.normal_table(seed + 1, Vt, D))))
+        net.dte.weight.copy_(dev(f32(gi.normal_table(seed + 2, 14, D))))
+        for lin, w in zip((ca.c_q, ca.c_k, ca.c_v, ca.c_proj), gi.digit_cross_weights(seed + 3, D)):
+            lin.weight.copy_(dev(w))
+    return z, net, T
+
+
+@pytest.mark.parametrize("case", gi.DIGIT_CROSS_CASES, ids=lambda c: c[0])
+def test_digit_cross_attn_modules_vs_reference(mot, case):
+    name, lf, mtpn, D, H, B, seed = case
+    z, net, T = build_digit(case)
+    assert sorted(net.digit_mixin.state_dict()) == ["cross_attn.c_k.weight", "cross_attn.c_proj.weight", "cross_attn.c_q.weight",
+                                                    "cross_attn.c_v.weight"]
+    with torch.no_grad():
+        x = net(dev(z[f"{name}/x_tokens"]), dev(z[f"{name}/x_digit_tokens"]))
+    mot.check_status()
+    assert x.shape == (B, T, D) and x.dtype == torch.float32
+    r32, r64 = z[f"{name}/f32/x"], z[f"{name}/f64/x"]
+    bar = 2 * max(np.abs(r32.astype(np.float64) - r64).max(), 1e-6 * np.abs(r64).max())
+    assert np.abs(host(x).astype(np.float64) - r64).max() <= bar
+    # one row alone gives the same values: rows of a batch do not see each other
+    with torch.no_grad():
+        x3 = net(dev(z[f"{name}/x_tokens"][3]), dev(z[f"{name}/x_digit_tokens"][3]))
+    assert torch.equal(x3.reshape(T, D), x[3])
+
+
+@pytest.mark.parametrize("case", gi.DIGIT_CROSS_CASES, ids=lambda c: c[0])
+def test_digit_cross_attn_backward_vs_reference_autograd(mot, case):
+    name, lf, mtpn, D, H, B, seed = case
+    z, net, T = build_digit(case)
+    x = net(dev(z[f"{name}/x_tokens"]), dev(z[f"{name}/x_digit_tokens"]))
+    (x * dev(z[f"{name}/g"])).sum().backward()
+    mot.check_status()
+    ca = net.digit_mixin.cross_attn
+    for key, p in (("d_tok", net.wte.weight), ("d_digit", net.dte.weight)):
+        full, rows = host(p.grad), z[f"{name}/{key}_rows"]
+        assert grel(full[rows], z[f"{name}/{key}_vals"]) <= GTOL, key
+        mask = np.ones(len(full), bool); mask[rows] = False
+        assert not full[mask].any(), key
+    for key, lin in (("d_cq", ca.c_q), ("d_ck", ca.c_k), ("d_cv", ca.c_v), ("d_cproj", ca.c_proj)):
+        assert grel(host(lin.weight.grad), z[f"{name}/{key}"]) <= GTOL, key
+
+
+def test_digit_cross_attn_errors(mot):
+    from mixture_of_tokenizers_amd import modules as M
+    with pytest.raises(AssertionError):                                 # model.py:241
+        M.make_digit_mixin(M.GPTConfig(n_embd_tok=256, n_embd_digit=128, n_head=2, digit_mixin_method="cross_attn"))
+    with pytest.raises(NotImplementedError, match="head_dim 128"):
+        M.make_digit_mixin(M.GPTConfig(n_embd_tok=256, n_embd_digit=256, n_head=4, digit_mixin_method="cross_attn"))
+    z, net, T = build_digit(gi.DIGIT_CROSS_CASES[1])
+    toks, digs = dev(z["runcfg/x_tokens"]), dev(z["runcfg/x_digit_tokens"])
+    with torch.no_grad():
+        with pytest.raises(AssertionError, match="KV length"):          # model.py:132
+            net(toks, digs[:, :-4])
+        with pytest.raises(AssertionError, match="Batch sizes"):        # model.py:129
+            net(toks, digs[:-1])
+        with pytest.raises(AssertionError, match="Digits must be provided"):   # model.py:321
+            net(toks)

@@ -320,6 +320,75 @@ def test_cross_attn_backward_oracle_vs_reference_autograd(case, modes):
         assert abs(got["lambda_factor"][0] - zg[f"{name}/{mode}/d_lambda"][0]) <= 1e-9 * max(1.0, abs(zg[f"{name}/{mode}/d_lambda"][0]))
 
 
+# ---------------------------------------------------------------------------------------------
+# mathblations cross-attention digit mixin (model.py:239-253 -> 89-154): the same oracle function, per-token heads
+# (the block mask q_idx == kv_idx // length_factor, line 111), lambda 1, rows of a batch laid end to end with the
+# rotary tables repeated per row
+# ---------------------------------------------------------------------------------------------
+def digit_cross_inputs(case, dt=np.float64):
+    name, lf, mtpn, D, H, B, seed = case
+    z = np.load(G / "digit_cross_attn.npz")
+    toks, digs = z[f"{name}/x_tokens"], z[f"{name}/x_digit_tokens"]
+    T = toks.shape[1]
+    Vt = 10 ** lf + 3
+    Wt, Wd = gi.normal_table(seed + 1, Vt, D).astype(dt), gi.normal_table(seed + 2, 14, D).astype(dt)
+    cq, ck, cv, cp = (w.astype(dt) for w in gi.digit_cross_weights(seed + 3, D))
+    rot = [np.tile(z[f"{name}/{k}"], (B, 1)) for k in ("cos_q", "sin_q", "cos_k", "sin_k")]
+    return z, toks.reshape(-1).astype(np.int32), digs.reshape(1, -1), T, Wt, Wd, cq, np.stack([ck, cv]), cp, rot
+
+
+@pytest.mark.parametrize("case", gi.DIGIT_CROSS_CASES, ids=lambda c: c[0])
+def test_digit_cross_attn_oracle_vs_reference(case):
+    name, lf, mtpn, D, H, B, seed = case
+    for dn, dt, tol in (("f32", np.float32, 2e-6), ("f64", np.float64, 1e-12)):
+        z, toks, digs, T, Wt, Wd, cq, kv, cp, rot = digit_cross_inputs(case, dt)
+        orc.set_rotary_f32_cast(False)       # apply_rotary_emb keeps the dtype of the head (model.py:51-58)
+        try:
+            x = orc.cross_attn(toks, digs, None, Wt, Wd, cq, kv, cp, 1.0, *rot, bpt=lf, n_heads=H, dtype=dt, head_layout=1)
+        finally:
+            orc.set_rotary_f32_cast(True)
+        ref = z[f"{name}/{dn}/x"].reshape(B * T, D)
+        assert np.abs(x - ref).max() <= tol * np.abs(ref).max(), dn
+
+
+@pytest.mark.parametrize("case", gi.DIGIT_CROSS_CASES, ids=lambda c: c[0])
+def test_digit_cross_attn_backward_oracle_vs_reference_autograd(case):
+    name, lf, mtpn, D, H, B, seed = case
+    z, toks, digs, T, Wt, Wd, cq, kv, cp, rot = digit_cross_inputs(case)
+    orc.set_rotary_f32_cast(False)
+    try:
+        got = orc.cross_attn_bwd(toks, digs, None, Wt, Wd, cq, kv, cp, 1.0, *rot, z[f"{name}/g"].reshape(1, B * T, D).astype(np.float64),
+                                 bpt=lf, n_heads=H, head_layout=1)
+    finally:
+        orc.set_rotary_f32_cast(True)
+    def close(a, b, what):
+        assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), what   # goldens are stored in float32
+    for key, full in (("d_tok", got["tok_table"]), ("d_digit", got["byte_table"])):
+        rows = z[f"{name}/{key}_rows"]
+        close(full[rows], z[f"{name}/{key}_vals"], key)
+        mask = np.ones(len(full), bool); mask[rows] = False
+        assert np.abs(full[mask]).max(initial=0.0) <= 1e-12 * np.abs(full).max(), key
+    close(got["q_w"], z[f"{name}/d_cq"], "c_q")
+    close(got["kv_w"][0], z[f"{name}/d_ck"], "c_k")
+    close(got["kv_w"][1], z[f"{name}/d_cv"], "c_v")
+    close(got["proj_w"], z[f"{name}/d_cproj"], "c_proj")
+
+
+def test_digit_rotary_tables_match_the_reference_bit_for_bit():
+    """modules.DigitRotary builds the bf16-valued cos/sin tables with the reference's torch expressions (model.py:32-49)."""
+    from mixture_of_tokenizers_amd.modules import DigitRotary
+    z = np.load(G / "digit_cross_attn.npz")
+    for name, lf, mtpn, D, H, B, seed in gi.DIGIT_CROSS_CASES:
+        T = z[f"{name}/x_tokens"].shape[1]
+        r = DigitRotary(D // H)
+        cq, sq = r.tables(T, 1, "cpu")
+        ck, sk = r.tables(T * lf, 2, "cpu")
+        np.testing.assert_array_equal(cq.numpy(), z[f"{name}/cos_q"])
+        np.testing.assert_array_equal(sq.numpy(), z[f"{name}/sin_q"])
+        np.testing.assert_array_equal(ck.numpy(), np.tile(z[f"{name}/cos_k"], (2, 1)))
+        np.testing.assert_array_equal(sk.numpy(), np.tile(z[f"{name}/sin_k"], (2, 1)))
+
+
 BF16_CONCAT_CASES = [("small", 97, 32, 8, 64, 8, 401), ("c2row", 512, 256, 32, 768, 16, 403)]
 
 
