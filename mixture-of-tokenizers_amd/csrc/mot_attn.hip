@@ -320,9 +320,7 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
             advance(pos, hk);
         }
     }
-    float mx = sc;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float mx = wave_max(sc);
     float p = lane < A.bpt ? expf(sc - mx) : 0.f;
     p /= wave_sum(p);
     // pass 2: dp_c = dy . v_c; dV_l rows

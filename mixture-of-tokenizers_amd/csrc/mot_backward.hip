@@ -64,12 +64,6 @@ struct BwdArgs {
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
 };
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 // element i of a float or bf16 array (uniform choice per launch)
 __device__ __forceinline__ float ld_in(const float *base, int64_t i, int bf16) {
     return bf16 ? (float)((const __bf16 *)base)[i] : base[i];

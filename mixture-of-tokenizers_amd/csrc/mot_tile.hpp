@@ -61,10 +61,32 @@ __device__ __forceinline__ int wave_rincl_min(int v, int lane) {
     }
     return v;
 }
+// Wave-wide reductions on the DPP cross-lane path (no LDS crossbar round trips): two quad permutes and two row rotates
+// leave every lane of a 16-lane row with the row's total; row_bcast:15 / row_bcast:31 then chain the four rows, so lane 63
+// holds the wave's total, which comes back as a wave-uniform (scalar) value.  6 VALU instructions + 1 readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float masked, float v) {   // lanes outside ROW_MASK keep `masked`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(masked), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E, kDppRowRor4 = 0x124, kDppRowRor8 = 0x128, kDppRowBcast15 = 0x142,
+              kDppRowBcast31 = 0x143;
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_move<kDppQuadXor1, 0xf>(0.f, v);
+    v += dpp_move<kDppQuadXor2, 0xf>(0.f, v);
+    v += dpp_move<kDppRowRor4, 0xf>(0.f, v);
+    v += dpp_move<kDppRowRor8, 0xf>(0.f, v);
+    v += dpp_move<kDppRowBcast15, 0xa>(0.f, v);
+    v += dpp_move<kDppRowBcast31, 0xc>(0.f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max(float v) {
+    v = fmaxf(v, dpp_move<kDppQuadXor1, 0xf>(v, v));
+    v = fmaxf(v, dpp_move<kDppQuadXor2, 0xf>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowRor4, 0xf>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowRor8, 0xf>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowBcast15, 0xa>(v, v));
+    v = fmaxf(v, dpp_move<kDppRowBcast31, 0xc>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // LDS carve-up of one tile.  SV = bpt|1 is the odd row stride of the per-slot arrays, which
