@@ -330,8 +330,10 @@ def main():
             read_bytes = 2 * 4 * D * tokens_per_step   # grad_out row + token row per position (byte rows and ids come from L2)
             res["backward"] = {"kernel": "embed_mix_bwd_full_kernel", "kernel_ms": bms, "tokens_per_s": tokens_per_step / (bms * 1e-3),
                                "hbm_read_GBps": read_bytes / (bms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
-                               "note": "one launch: in-LDS bitonic grouping by token, register runs -> fp32 atomic row-adds, "
-                                       "byte-table gradient in 64-bit fixed point in LDS"}
+                               "note": "whole backward call: positions grouped by token with a counting sort (bwd_rank / bwd_scan / bwd_place), "
+                                       "then one scatter kernel -- a token row is read and its gradient row flushed (fp32 atomic "
+                                       "row-add) once per run, byte-table gradient in 64-bit fixed point in LDS; hbm_read counts the "
+                                       "algorithmic grad_out row + token row per position"}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, inp, args.cpu_seconds)
         print(json.dumps(res), flush=True)

@@ -58,8 +58,8 @@ struct BwdArgs {
     // byte-table gradient privatised in LDS as 64-bit fixed point: rows [0, priv_lo) and [priv_hi0, byte_rows) have a slot
     // (everything when the table fits; otherwise the raw byte values and the trailing specials such as pad / eot)
     int priv_lo, priv_hi0, priv_rows;
-    int chunk;  // embed_mix_bwd_full_kernel: positions per LDS-sorted chunk (power of two <= kChunkMax)
     const int32_t *pos_sorted;  // token positions ordered by token id
+    const int32_t *tok_sorted;  // their (clamped) token ids
     int in_bf16;  // tables and grad_out are bf16 (gradients are accumulated and returned in fp32 either way)
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
 };
@@ -341,18 +341,17 @@ __device__ __forceinline__ unsigned long long to_fixed(float v, int k) {
     return (unsigned long long)(__double_as_longlong(d) - 0x4338000000000000ll);
 }
 
-constexpr int kChunkMax = 2048;   // positions one workgroup sorts in LDS at a time (11 index bits next to the token id)
 
-template <int MODE, int NE>
+template <int MODE, int NE, bool BF>   // BF: tables and grad_out are bf16 (SUM / NOOP; the CONCAT_LINEAR path widens its operands first)
 __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const BwdArgs A) {
     constexpr int D = 64 * NE;
     extern __shared__ unsigned long long lds_q[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar loop control below
     const int nbyte = A.priv_rows * A.Db;
     unsigned long long *dbyte_q = lds_q;
     unsigned long long *seg_q = lds_q + nbyte + wave * kMaxBpt;                      // per-wave per-slot sums (byte-norm backward)
     uint32_t *fx_bits = (uint32_t *)(lds_q + nbyte + kBwdWaves * kMaxBpt);
-    uint32_t *skey = fx_bits + 4;                                                    // [chunk] (token << 11 | index in chunk), sorted
     for (int i = tid; i < nbyte; i += kBwdThreads) dbyte_q[i] = 0ull;
     if (tid == 0) *fx_bits = 0u;
     // SPLIT: the gradient row is du of CONCAT_LINEAR -- [token part | byte part] (or the reverse), every 64-element
@@ -371,140 +370,150 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     float ds_t = 0.f, ds_b = 0.f;
-    int slw[NE];   // element lane + 64 j of a row: byte slot in bits 16.., index within the slot in bits 0..15
+    // element lane + 64 j of a row: ds_bpermute address of its byte slot's lane (slot * 4) and byte offset of the element
+    // within a byte-table row, for 4-byte elements (x2 in the 64-bit LDS copy, /2 for bf16 tables)
+    int sl4[NE], wi4[NE];
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
         const int eb = max(lane + 64 * j - A.byte_lo, 0), sl = BYTES ? eb / A.Db : 0;
-        slw[j] = (sl << 16) | (eb - sl * A.Db);
+        sl4[j] = sl * 4;
+        wi4[j] = (eb - sl * A.Db) * 4;
     }
-    // fixed-point scale of the privatised byte-table sums (see embed_mix_bwd_kernel): chosen per workgroup from the
-    // upstream gradient rows of the waves' first positions, v * 2^fx_k with the sample's max |g * scale_byte| at 2^24.
-    // Terms that would land outside [2^12, 2^40) -- and rows without a slot -- take the exact global atomic.
+    constexpr uint32_t esz = BF ? 2u : 4u;
+    const uint32_t loff = (uint32_t)lane * esz;   // byte offset of a lane's first element in a row
+    const uint32_t row8 = (uint32_t)A.Db * 8u;
+    // Rows are addressed as (wave-uniform base pointer) + (32-bit byte offset): the position and its token id are made
+    // scalar with readfirstlane, so a row's 64-bit address lives in SGPRs and the per-element offsets are immediates.
+    auto ldf = [&](const void *sbase, uint32_t boff) -> float {
+        const char *q = (const char *)sbase + boff;
+        if constexpr (BF) return (float)*(const __bf16 *)q;
+        else return *(const float *)q;
+    };
+    // fixed-point scale of the privatised byte-table sums: chosen per workgroup from the upstream gradient rows of the
+    // waves' first positions, v * 2^fx_k with the sample's max |g * scale_byte| at 2^27, so that a term converts through
+    // a 32-bit integer.  Terms outside [2^12, 2^31) after scaling -- up to 16x the sample's maximum, down to 2^-15 of
+    // it -- non-finite terms and rows without a slot take the exact global float atomic in a separate, rarely entered
+    // block; the common path is straight-line (a term that must not be added there is replaced by zero).
     int fx_k = 0;
-    float fx_hi = 0.f, fx_lo = 0.f;
+    uint32_t fx_lo_bits = 0, fx_span = 0;
     bool fx_known = !BYTES;
     auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
-    auto add_byte = [&](int id, int wi, float v) {
-        const int sl = byte_slot(id);
-        const float av = fabsf(v);
-        if (sl >= 0 && av < fx_hi && (av >= fx_lo || av == 0.f)) atomicAdd(dbyte_q + sl * A.Db + wi, to_fixed(v, fx_k));
-        else atomicAdd(A.d_byte + id * A.Db + wi, v);
+    auto in_range = [&](float v) { return ((__float_as_uint(v) & 0x7fffffffu) - fx_lo_bits) < fx_span; };
+    auto add_fixed = [&](int lrow, int j, float v) {   // lrow: byte offset of the row in dbyte_q (>= 0)
+        const int q = __float2int_rn(ldexpf(v, fx_k));
+        atomicAdd((unsigned long long *)((char *)dbyte_q + (uint32_t)(lrow + 2 * wi4[j])), (unsigned long long)(long long)q);
     };
 
-    float acc[NE];
+    float acc[NE], an[NE];   // the current run: gradient of the token's table row so far, its (normalised) table row
+    float ra = 1.f;          // 1 / rms of that row
     int cur = -1;
     auto flush = [&]() {
         if (cur < 0 || (A.abl & 2)) return;
-        float *drow = A.d_tok + (int64_t)cur * A.Dt + lane - A.tok_lo;
+        char *drow = (char *)(A.d_tok + ((int64_t)((A.abl & 32) ? 0 : cur) * A.Dt - A.tok_lo));   // abl 32: one hot row
+        if (A.abl & 16) {   // abl 16: plain stores
+#pragma unroll
+            for (int j = 0; j < NE; ++j) *(float *)(drow + ((uint32_t)lane * 4u + 256u * j)) = acc[j];
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NE; ++j)
-            if (tmask >> j & 1) atomicAdd(drow + 64 * j, acc[j]);
+            if (tmask >> j & 1) atomicAdd((float *)(drow + ((uint32_t)lane * 4u + 256u * j)), acc[j]);
     };
     auto load_id = [&](const int64_t *ids, int64_t n) {   // lanes < bpt: the token's byte ids, clamped once
         int64_t v = 0;
         if (lane < A.bpt) {
-            v = ids[n * A.bpt + lane];
+            v = *(const int64_t *)((const char *)(ids + n * A.bpt) + (uint32_t)lane * 8u);
             if ((uint64_t)v >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); v = 0; }
         }
         return (int)v;
     };
-    const int chunk = A.chunk, per_wave = chunk / kBwdWaves;
-    const int64_t nchunks = (A.n_tokens + chunk - 1) / chunk;
-    for (int64_t c = blockIdx.x; c < nchunks; c += gridDim.x) {
-        // ---- group this chunk's positions by token id: bitonic sort of (token << 11 | index) in LDS.  Equal tokens
-        // become runs, so a run costs one atomic row-add; no global histogram / scan / scatter, no sorted index in HBM.
-        const int64_t base = c * chunk;
-        __syncthreads();   // the previous chunk's keys are no longer read (also orders the table zeroing above)
-        for (int i = tid; i < chunk; i += kBwdThreads) {
-            uint32_t key = 0xffffffffu;
-            if (base + i < A.n_tokens) {
-                uint32_t t = (uint32_t)A.tokens[base + i];
-                if ((uint64_t)t >= (uint64_t)A.tok_rows) { if (A.status) atomicOr(A.status, kStatusTokenOor); t = 0; }
-                key = (t << 11) | (uint32_t)i;
-            }
-            skey[i] = key;
+    // ---- positions come grouped by token id (A.pos_sorted / A.tok_sorted, the counting sort above): a workgroup takes a
+    // contiguous share of the sorted order and a wave a contiguous eighth of that, so a token's positions form a run
+    // inside a wave -- its table row is read once and its gradient row leaves with one atomic row-add per run (plus one
+    // where a run crosses a wave boundary).  A wave reads 64 (position, token) pairs at a time and hands them out with
+    // readlane, keeping the loop control scalar.
+    const int64_t per_wg = (A.n_tokens + gridDim.x - 1) / gridDim.x;
+    const int64_t wg_lo = min(A.n_tokens, (int64_t)blockIdx.x * per_wg), wg_hi = min(A.n_tokens, wg_lo + per_wg);
+    const int64_t per_wave = (wg_hi - wg_lo + kBwdWaves - 1) / kBwdWaves;
+    const int64_t s_begin = min(wg_hi, wg_lo + wave * per_wave), s_end = min(wg_hi, s_begin + per_wave);
+    __syncthreads();   // orders the table zeroing above
+    if (!fx_known) {   // uniform: every wave takes part, once per workgroup
+        float gmax = 0.f;
+        if (s_begin < s_end) {
+            const char *grow = (const char *)A.grad_out + (int64_t)A.pos_sorted[s_begin] * D * (int64_t)esz;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) gmax = fmaxf(gmax, fabsf(ldf(grow, loff + 64u * esz * j)));
+            gmax = wave_max(gmax) * fabsf(s_byte);
+            if (lane == 0 && gmax > 0.f && gmax < INFINITY) atomicMax(fx_bits, __float_as_uint(gmax));
         }
         __syncthreads();
-        for (int k = 2; k <= chunk; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int p = tid; p < chunk / 2; p += kBwdThreads) {
-                    const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
-                    const uint32_t x = skey[i], y = skey[ixj];
-                    if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[ixj] = x; }
-                }
-                __syncthreads();
-            }
-        const int s_begin = wave * per_wave, s_end = s_begin + per_wave;
-        if (!fx_known) {   // uniform: every wave takes part, once per workgroup
-            const uint32_t key = skey[s_begin];
-            float gmax = 0.f;
-            if (key != 0xffffffffu) {
-                const int64_t grow = (base + (key & 2047)) * D + lane;
-#pragma unroll
-                for (int j = 0; j < NE; ++j)
-                    gmax = fmaxf(gmax, fabsf(A.in_bf16 ? (float)((const __bf16 *)A.grad_out)[grow + 64 * j] : A.grad_out[grow + 64 * j]));
-                gmax = wave_max(gmax) * fabsf(s_byte);
-                if (lane == 0 && gmax > 0.f && gmax < INFINITY) atomicMax(fx_bits, __float_as_uint(gmax));
-            }
-            __syncthreads();
-            const float m = __uint_as_float(*fx_bits);
-            fx_k = m > 0.f ? 24 - ilogbf(m) : 0;
-            fx_hi = ldexpf(1.0f, 40 - fx_k);
-            fx_lo = ldexpf(1.0f, 12 - fx_k);
-            fx_known = true;
-        }
-        uint32_t key_nx = skey[s_begin];
+        const float m = __uint_as_float(*fx_bits);
+        fx_k = m > 0.f ? min(27 - ilogbf(m), 100) : 0;
+        fx_lo_bits = __float_as_uint(ldexpf(1.0f, 12 - fx_k));
+        fx_span = __float_as_uint(ldexpf(1.0f, 31 - fx_k)) - fx_lo_bits;
+        fx_known = true;
+    }
+    for (int64_t s0 = s_begin; s0 < s_end; s0 += 64) {
+        const int cnt = (int)min((int64_t)64, s_end - s0);
+        int vpos = 0, vtok = 0;
+        if (lane < cnt) { vpos = A.pos_sorted[s0 + lane]; vtok = A.tok_sorted[s0 + lane]; }
+        int n_nx = __builtin_amdgcn_readfirstlane(vpos);
         int ida_nx = 0, idb_nx = 0;
-        if (BYTES && key_nx != 0xffffffffu) {
-            ida_nx = load_id(A.ids_a, base + (key_nx & 2047));
-            if (dual) idb_nx = load_id(A.ids_b, base + (key_nx & 2047));
+        if (BYTES) {
+            ida_nx = load_id(A.ids_a, n_nx);
+            if (dual) idb_nx = load_id(A.ids_b, n_nx);
         }
-        for (int si = s_begin; si < s_end; ++si) {
-            const uint32_t key = key_nx;
-            if (key == 0xffffffffu) break;   // padding of the last chunk sorts to the end
-            const int64_t n = base + (key & 2047);
-            const int tok = (int)(key >> 11), ida = ida_nx, idb = idb_nx;
-            key_nx = si + 1 < s_end ? skey[si + 1] : 0xffffffffu;
-            if (tok != cur) {
+        for (int k = 0; k < cnt; ++k) {
+            const int64_t n = n_nx;
+            const int tok = __builtin_amdgcn_readlane(vtok, k), ida = ida_nx, idb = idb_nx;
+            const bool more = k + 1 < cnt;
+            if (more) n_nx = __builtin_amdgcn_readlane(vpos, k + 1);
+
+            float bn[NE], dy[NE];
+            int lra[NE], lrb[NE];   // byte offset of the element's row in the LDS copy (negative: no slot), first / second id tensor
+            const char *grow = (const char *)A.grad_out + n * D * (int64_t)esz;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) dy[j] = ldf(grow, loff + 64u * esz * j);
+            if (tok != cur) {   // a new run: the previous token's gradient row leaves, this token's (normalised) row comes in
                 flush();
                 cur = tok;
-#pragma unroll
-                for (int j = 0; j < NE; ++j) acc[j] = 0.f;
-            }
-            float an[NE], bn[NE], dy[NE];
-            int idj[NE];
-            const int64_t trow = (int64_t)tok * A.Dt + lane - A.tok_lo, grow = n * D + lane;
-            if (!SPLIT && A.in_bf16) {
+                const char *trow = (const char *)A.tok_table + ((int64_t)tok * A.Dt - A.tok_lo) * (int64_t)esz;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
-                    an[j] = (float)((const __bf16 *)A.tok_table)[trow + 64 * j];
-                    dy[j] = (float)((const __bf16 *)A.grad_out)[grow + 64 * j];
+                    acc[j] = 0.f;
+                    an[j] = (tmask >> j & 1) ? ldf(trow, loff + 64u * esz * j) : 0.f;
                 }
-            } else {
+                ra = 1.f;
+                if (A.norm_tok) {
+                    float ss = 0.f;
 #pragma unroll
-                for (int j = 0; j < NE; ++j) {
-                    an[j] = (tmask >> j & 1) ? A.tok_table[(A.abl & 8) ? lane + 64 * j : trow + 64 * j] : 0.f;   // abl 8: one hot row
-                    dy[j] = A.grad_out[(A.abl & 8) ? lane + 64 * j : grow + 64 * j];
+                    for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
+                    ra = rms_scale(wave_sum(ss), A.Dt, A.eps);
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) an[j] *= ra;
                 }
             }
             if (BYTES) {
+                // lanes < bpt: gather offset of the slot's byte row and offset of its LDS row (or -1)
+                const int ga = ida * A.Db * (int)esz, gb = idb * A.Db * (int)esz;
+                const int sa = byte_slot(ida), sb = byte_slot(idb);
+                const int la = sa >= 0 ? sa * (int)row8 : -1, lb = sb >= 0 ? sb * (int)row8 : -1;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
-                    bn[j] = 0.f; idj[j] = 0;
+                    bn[j] = 0.f; lra[j] = 0; lrb[j] = 0;
                     if (!(bmask >> j & 1)) continue;
-                    const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
-                    idj[j] = __shfl(ida, sl, 64);
-                    const int64_t o1 = (int64_t)idj[j] * A.Db + wi;
-                    float v = A.in_bf16 ? (float)((const __bf16 *)A.byte_table)[o1] : A.byte_table[o1];
+                    const uint32_t w = BF ? (uint32_t)wi4[j] >> 1 : (uint32_t)wi4[j];
+                    float v = ldf(A.byte_table, (uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], ga) + w);
+                    lra[j] = __builtin_amdgcn_ds_bpermute(sl4[j], la);
                     if (dual) {
-                        const int64_t o2 = (int64_t)__shfl(idb, sl, 64) * A.Db + wi;
-                        v += A.in_bf16 ? (float)((const __bf16 *)A.byte_table)[o2] : A.byte_table[o2];
+                        v += ldf(A.byte_table, (uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], gb) + w);
+                        lrb[j] = __builtin_amdgcn_ds_bpermute(sl4[j], lb);
                     }
                     bn[j] = v;
                 }
-                if (key_nx != 0xffffffffu) {   // the next position's byte ids while this one's rows are in flight
-                    ida_nx = load_id(A.ids_a, base + (key_nx & 2047));
-                    if (dual) idb_nx = load_id(A.ids_b, base + (key_nx & 2047));
+                if (more) {   // the next position's byte ids while this one's rows are in flight
+                    ida_nx = load_id(A.ids_a, n_nx);
+                    if (dual) idb_nx = load_id(A.ids_b, n_nx);
                 }
             }
             float rnb = 1.f;   // lanes < bpt: 1/rms of the slot's byte row
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     __threadfence_block();
 #pragma unroll
                     for (int j = 0; j < NE; ++j)
-                        if (bmask >> j & 1) atomicAdd(seg_q + (slw[j] >> 16), to_fixed(bn[j] * bn[j], kk));
+                        if (bmask >> j & 1) atomicAdd(seg_q + (sl4[j] >> 2), to_fixed(bn[j] * bn[j], kk));
                     __threadfence_block();
                     rnb = rms_scale((float)ldexp((double)(long long)seg_q[lane], -kk), A.Db, A.eps);
                     __threadfence_block();
@@ -527,18 +536,9 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     rnb = A.byte_rnorm[ida];
                 }
 #pragma unroll
-                for (int j = 0; j < NE; ++j) bn[j] *= __shfl(rnb, slw[j] >> 16, 64);
+                for (int j = 0; j < NE; ++j) bn[j] *= __int_as_float(__builtin_amdgcn_ds_bpermute(sl4[j], __float_as_int(rnb)));
             }
-            // ---- forward scalars, then back through the output norm
-            float ra = 1.f;
-            if (A.norm_tok) {
-                float ss = 0.f;
-#pragma unroll
-                for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
-                ra = rms_scale(wave_sum(ss), A.Dt, A.eps);
-#pragma unroll
-                for (int j = 0; j < NE; ++j) an[j] *= ra;
-            }
+            // ---- back through the output norm
             if (A.norm_out) {
                 float ss = 0.f, m = 0.f;
 #pragma unroll
@@ -588,23 +588,47 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     __threadfence_block();
 #pragma unroll
                     for (int j = 0; j < NE; ++j)
-                        if (bmask >> j & 1) atomicAdd(seg_q + (slw[j] >> 16), to_fixed(dy[j] * bn[j], kk));
+                        if (bmask >> j & 1) atomicAdd(seg_q + (sl4[j] >> 2), to_fixed(dy[j] * bn[j], kk));
                     __threadfence_block();
                     float sg = (float)ldexp((double)(long long)seg_q[lane], -kk) / (float)A.Db;
                     if (!(pmax < INFINITY)) sg = NAN;   // non-finite gradients stay non-finite
 #pragma unroll
                     for (int j = 0; j < NE; ++j) {
-                        const int sl = slw[j] >> 16;
-                        dy[j] = __shfl(rnb, sl, 64) * (dy[j] - bn[j] * __shfl(sg, sl, 64));
+                        const float rj = __int_as_float(__builtin_amdgcn_ds_bpermute(sl4[j], __float_as_int(rnb)));
+                        const float sj = __int_as_float(__builtin_amdgcn_ds_bpermute(sl4[j], __float_as_int(sg)));
+                        dy[j] = rj * (dy[j] - bn[j] * sj);
                     }
                     __threadfence_block();
                 }
+                if (!(A.abl & 1)) {
+                    bool slow = false;   // some element of this lane needs the exact path
 #pragma unroll
-                for (int j = 0; j < NE; ++j) {
-                    if (!(bmask >> j & 1) || (A.abl & 1)) continue;
-                    const int sl = slw[j] >> 16, wi = slw[j] & 0xffff;
-                    add_byte(idj[j], wi, dy[j]);
-                    if (dual) add_byte(__shfl(idb, sl, 64), wi, dy[j]);
+                    for (int j = 0; j < NE; ++j) {
+                        if (!(bmask >> j & 1)) continue;
+                        const bool inr = in_range(dy[j]), nz = (__float_as_uint(dy[j]) << 1) != 0u;
+                        const bool oka = inr && lra[j] >= 0;
+                        add_fixed(max(lra[j], 0), j, oka ? dy[j] : 0.f);
+                        slow |= nz && !oka;
+                        if (dual) {
+                            const bool okb = inr && lrb[j] >= 0;
+                            add_fixed(max(lrb[j], 0), j, okb ? dy[j] : 0.f);
+                            slow |= nz && !okb;
+                        }
+                    }
+                    if (__any(slow)) {
+#pragma unroll
+                        for (int j = 0; j < NE; ++j) {
+                            if (!(bmask >> j & 1)) continue;
+                            const bool inr = in_range(dy[j]), nz = (__float_as_uint(dy[j]) << 1) != 0u;
+                            const int wi = wi4[j] >> 2;
+                            const int ia = __builtin_amdgcn_ds_bpermute(sl4[j], ida);
+                            if (nz && !(inr && lra[j] >= 0)) atomicAdd(A.d_byte + ia * A.Db + wi, dy[j]);
+                            if (dual) {
+                                const int ib = __builtin_amdgcn_ds_bpermute(sl4[j], idb);
+                                if (nz && !(inr && lrb[j] >= 0)) atomicAdd(A.d_byte + ib * A.Db + wi, dy[j]);
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -624,40 +648,107 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     }
 }
 
-// ---- counting sort of the token positions by (clamped) token id
-__global__ __launch_bounds__(kThreads) void bwd_hist_kernel(const int32_t *__restrict__ tokens, int64_t n, int64_t rows,
-                                                            int32_t *__restrict__ counts) {
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-        int t = tokens[i];
-        if ((uint64_t)(uint32_t)t >= (uint64_t)rows) t = 0;
-        atomicAdd(&counts[t], 1);
+// ---- grouping of the token positions by (clamped) token id: a counting sort in three small kernels.
+// bwd_rank_kernel: a workgroup sorts (token << 11 | index) for 2048 positions in LDS (bitonic), so equal tokens become
+// runs; the head of a run reserves the run's places in the token's group with ONE atomicAdd(counts[token], length)
+// (a hot token costs one atomic per workgroup, not one per occurrence) and every position gets its rank in the group.
+// bwd_scan_kernel: group starts.  bwd_place_kernel: pos_sorted[start[token] + rank] = position (no atomics).
+constexpr int kRankThreads = 512;
+__device__ __forceinline__ int lower_bound_u32(const uint32_t *a, int n, uint32_t v) {   // first index with a[i] >= v
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+template <int kRankChunk>   // positions per workgroup: 2048, or 512 when there are too few positions to fill the chip with 2048s
+__global__ __launch_bounds__(kRankThreads) void bwd_rank_kernel(const int32_t *__restrict__ tokens, int64_t n, int64_t rows,
+                                                                int32_t *__restrict__ counts, int32_t *__restrict__ rank,
+                                                                uint32_t *status) {
+    __shared__ uint32_t skey[kRankChunk];
+    __shared__ int32_t runbase[kRankChunk];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * kRankChunk;
+    for (int i = tid; i < kRankChunk; i += kRankThreads) {
+        uint32_t key = 0xffffffffu;
+        if (base + i < n) {
+            uint32_t t = (uint32_t)tokens[base + i];
+            if ((uint64_t)t >= (uint64_t)rows) { if (status) atomicOr(status, kStatusTokenOor); t = 0; }
+            key = (t << 11) | (uint32_t)i;
+        }
+        skey[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= kRankChunk; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int p = tid; p < kRankChunk / 2; p += kRankThreads) {
+                const int i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), ixj = i | j;
+                const uint32_t x = skey[i], y = skey[ixj];
+                if ((x > y) == ((i & k) == 0)) { skey[i] = y; skey[ixj] = x; }
+            }
+            __syncthreads();
+        }
+    constexpr int kPer = kRankChunk / kRankThreads;
+    int head[kPer];
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+        const int si = tid + r * kRankThreads;
+        const uint32_t key = skey[si];
+        head[r] = -1;
+        if (key == 0xffffffffu) continue;
+        const uint32_t tok = key >> 11;
+        const int h = (si == 0 || (skey[si - 1] >> 11) != tok) ? si : lower_bound_u32(skey, si, tok << 11);
+        head[r] = h;
+        if (h == si) {
+            const int e = lower_bound_u32(skey, kRankChunk, (tok + 1) << 11);   // padding keys are larger than any token's
+            runbase[si] = atomicAdd(&counts[tok], e - si);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kPer; ++r) {
+        const int si = tid + r * kRankThreads;
+        if (head[r] < 0) continue;
+        rank[base + (skey[si] & 2047)] = runbase[head[r]] + (si - head[r]);
     }
 }
 
-// exclusive scan of counts[0..rows) into starts (one 1024-thread workgroup; rows <= a few 100 k)
+__global__ __launch_bounds__(kThreads) void bwd_place_kernel(const int32_t *__restrict__ tokens, int64_t n, int64_t rows,
+                                                             const int32_t *__restrict__ starts, const int32_t *__restrict__ rank,
+                                                             int32_t *__restrict__ pos_sorted, int32_t *__restrict__ tok_sorted) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        int t = tokens[i];
+        if ((uint64_t)(uint32_t)t >= (uint64_t)rows) t = 0;
+        const int32_t at = starts[t] + rank[i];
+        pos_sorted[at] = (int32_t)i;
+        tok_sorted[at] = t;
+    }
+}
+
+// exclusive scan of counts[0..rows) into starts.  Workgroup b owns the 1024 counts of tile b: it first sums everything in
+// front of its tile (coalesced reads of an L2-resident array, at most a few hundred KB), then scans its own tile.
 __global__ __launch_bounds__(1024) void bwd_scan_kernel(const int32_t *__restrict__ counts, int64_t rows,
                                                         int32_t *__restrict__ starts) {
     __shared__ int32_t wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t per = (rows + 1023) / 1024, lo = min(rows, tid * per), hi = min(rows, lo + per);
-    int32_t s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += counts[i];
-    const int32_t incl = wave_incl_add(s, lane);
-    if (lane == 63) wsum[wave] = incl;
+    const int64_t t0 = (int64_t)blockIdx.x * 1024;
+    int32_t before = 0;
+    for (int64_t i = tid; i < t0; i += 1024) before += counts[i];
+    const int64_t i = t0 + tid;
+    const int32_t own = i < rows ? counts[i] : 0;
+    const int32_t incl = wave_incl_add(own, lane);
+    const int32_t bsum = wave_incl_add(before, lane);
+    if (lane == 63) wsum[wave] = incl + bsum;     // this wave's share of (everything before the tile + the tile)
     __syncthreads();
-    int32_t off = incl - s;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    for (int64_t i = lo; i < hi; ++i) { starts[i] = off; off += counts[i]; }
-}
-
-__global__ __launch_bounds__(kThreads) void bwd_scatter_kernel(const int32_t *__restrict__ tokens, int64_t n, int64_t rows,
-                                                               const int32_t *__restrict__ starts, int32_t *__restrict__ cursor,
-                                                               int32_t *__restrict__ pos_sorted) {
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-        int t = tokens[i];
-        if ((uint64_t)(uint32_t)t >= (uint64_t)rows) t = 0;
-        pos_sorted[starts[t] + atomicAdd(&cursor[t], 1)] = (int32_t)i;
-    }
+    int32_t off = incl - own;
+    for (int w = 0; w < 16; ++w) off += w < wave ? wsum[w] : 0;
+    // the `before` parts of the later waves belong in front of every element of the tile as well
+    __shared__ int32_t bpart[16];
+    if (lane == 63) bpart[wave] = bsum;
+    __syncthreads();
+    for (int w = wave; w < 16; ++w) off += bpart[w];
+    if (i < rows) starts[i] = off;
 }
 
 template <int MODE, int NE>
@@ -674,18 +765,28 @@ static int launch_bwd(const BwdArgs &A, size_t lds, hipStream_t stream) {
     return check_launch("embed_mix_bwd_kernel");
 }
 
-template <int MODE, int NE>
-static int launch_bwd_full(const BwdArgs &A, size_t lds, hipStream_t stream) {
+template <int MODE, int NE, bool BF>
+static int launch_bwd_full_t(const BwdArgs &A, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_bwd_full_kernel<MODE, NE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_bwd_full_kernel<MODE, NE, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_bwd_full_kernel): %s", hipGetErrorString(e));
         attr_set = true;
     }
-    int64_t blocks = (A.n_tokens + A.chunk - 1) / A.chunk;
-    if (blocks > 256) blocks = 256;   // one persistent workgroup per CU
-    hipLaunchKernelGGL((embed_mix_bwd_full_kernel<MODE, NE>), dim3((unsigned)blocks), dim3(kBwdThreads), lds, stream, A);
+    int64_t blocks = (A.n_tokens + 16 * kBwdWaves - 1) / (16 * kBwdWaves);   // >= 16 sorted positions per wave
+    if (blocks > 256) blocks = 256;   // one workgroup per CU
+    hipLaunchKernelGGL((embed_mix_bwd_full_kernel<MODE, NE, BF>), dim3((unsigned)blocks), dim3(kBwdThreads), lds, stream, A);
     return check_launch("embed_mix_bwd_full_kernel");
+}
+
+template <int MODE, int NE>
+static int launch_bwd_full(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
+        if (A.in_bf16) return launch_bwd_full_t<MODE, NE, true>(A, lds, stream);
+    } else if (A.in_bf16) {
+        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: the CONCAT_LINEAR scatter takes fp32 operands");
+    }
+    return launch_bwd_full_t<MODE, NE, false>(A, lds, stream);
 }
 
 // rows that are "full" (see embed_mix_bwd_full_kernel): SUM / NOOP, D a multiple of 64 with a built NE
@@ -698,8 +799,7 @@ static bool full_layout(const BwdArgs &A) {
         if (A.Dt != A.D || A.tok_lo != 0) return false;
         if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D || A.Db > 0xffff)) return false;
     }
-    if ((A.abl & 4) || A.tok_rows > (1 << 20)) return false;   // abl 4: dev switch back to the general kernel
-   // (token << 11 | index) must stay below the 0xffffffff sentinel
+    if (A.abl & 4) return false;   // abl 4: dev switch back to the general kernel
     const int ne = A.D / 64;
     return ne == 1 || ne == 2 || ne == 4 || ne == 8 || ne == 12 || ne == 16 || ne == 24 || ne == 32;
 }
@@ -734,9 +834,9 @@ static int dispatch_ne(const BwdArgs &A, size_t lds, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------------
 // scatter stage shared by all modes: sort the positions by token id, then embed_mix_bwd_kernel.
-// `ws_ints` = [counts: tok_rows][cursor: tok_rows][starts: tok_rows][pos_sorted: N] (int32).
+// `ws_ints` = [counts: tok_rows][starts: tok_rows][rank: N][pos_sorted: N][tok_sorted: N] (int32).
 // ------------------------------------------------------------------------------------------
-static size_t scatter_ws_ints(const MotEmbedMixDesc &d) { return 3 * (size_t)d.tok_rows + (size_t)(d.n_rows * d.tokens_per_row); }
+static size_t scatter_ws_ints(const MotEmbedMixDesc &d) { return 2 * (size_t)d.tok_rows + 3 * (size_t)(d.n_rows * d.tokens_per_row); }
 
 template <int MODE>
 static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, float *rnorm_ws, hipStream_t stream) {
@@ -745,26 +845,30 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
 #ifdef MOT_DEV_ABLATION
     if (getenv("MOT_BWD_ABL")) A.abl = atoi(getenv("MOT_BWD_ABL"));
 #endif
+    if (d.tok_rows >= (1 << 21) - 1)   // (token << 11 | index) of bwd_rank_kernel must stay below its 0xffffffff padding key
+        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: token tables of %lld rows (>= 2^21 - 1) are not built", (long long)d.tok_rows);
     const bool full = full_layout<MODE>(A);
     size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
-    if (full) {
-        // the lean kernel groups positions by token inside LDS, chunk by chunk: >= 256 chunks when there are enough tokens
-        int chunk = 256;
-        while (chunk < kChunkMax && (A.n_tokens + chunk - 1) / chunk > 256) chunk <<= 1;
-        A.chunk = chunk;
-        lds += (size_t)chunk * sizeof(uint32_t);
-    } else {
-        int32_t *counts = ws_ints, *cursor = counts + d.tok_rows, *starts = cursor + d.tok_rows, *pos_sorted = starts + d.tok_rows;
-        hipError_t e = hipMemsetAsync(counts, 0, 2 * (size_t)d.tok_rows * sizeof(int32_t), stream);  // counts + cursor
+    {
+        int32_t *counts = ws_ints, *starts = counts + d.tok_rows, *rank = starts + d.tok_rows, *pos_sorted = rank + A.n_tokens,
+                *tok_sorted = pos_sorted + A.n_tokens;
+        hipError_t e = hipMemsetAsync(counts, 0, (size_t)d.tok_rows * sizeof(int32_t), stream);
         if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
-        int64_t hb = (A.n_tokens + kThreads - 1) / kThreads;
-        if (hb > 2048) hb = 2048;
-        hipLaunchKernelGGL(bwd_hist_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts);
-        hipLaunchKernelGGL(bwd_scan_kernel, dim3(1), dim3(1024), 0, stream, counts, A.tok_rows, starts);
-        hipLaunchKernelGGL(bwd_scatter_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows,
-                           starts, cursor, pos_sorted);
+        const int rank_chunk = A.n_tokens >= 256 * 2048 ? 2048 : 512;
+        const int64_t rb = (A.n_tokens + rank_chunk - 1) / rank_chunk;
+        int64_t pb = (A.n_tokens + kThreads - 1) / kThreads;
+        if (pb > 2048) pb = 2048;
+        if (rb > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: too many positions");
+        if (rank_chunk == 2048)
+            hipLaunchKernelGGL(bwd_rank_kernel<2048>, dim3((unsigned)rb), dim3(kRankThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts, rank, A.status);
+        else
+            hipLaunchKernelGGL(bwd_rank_kernel<512>, dim3((unsigned)rb), dim3(kRankThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts, rank, A.status);
+        hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)((A.tok_rows + 1023) / 1024)), dim3(1024), 0, stream, counts, A.tok_rows, starts);
+        hipLaunchKernelGGL(bwd_place_kernel, dim3((unsigned)pb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, starts, rank,
+                           pos_sorted, tok_sorted);
         if ((rc = check_launch("embed_mix_bwd sort kernels"))) return rc;
         A.pos_sorted = pos_sorted;
+        A.tok_sorted = tok_sorted;
 #ifdef MOT_DEV_ABLATION
         if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
 #endif
