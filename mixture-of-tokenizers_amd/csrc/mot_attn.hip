@@ -207,8 +207,7 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     int rc;
     hipLaunchKernelGGL(iota32_kernel, dim3(256), dim3(kThreads), 0, stream, iota, n_iota);
     if ((rc = check_launch("iota32_kernel"))) return rc;
-    hipError_t e = hipMemsetAsync(byte0, 0, 16, stream);
-    if (e != hipSuccess) return set_error(MOT_EHIP, "cross_attn: hipMemsetAsync: %s", hipGetErrorString(e));
+    if ((rc = launch_zero_words(byte0, 4, stream))) return rc;
     MotEmbedMixDesc g;
     // 1. q = W_q norm?(E_t[tok])          (train_gpt.py:348-377 + 277)
     dense_desc(g, d.tokens, byte0, d.tok_table, d.tok_rows, T, D, d.q_w, HD, q, d.status, lin, lin_bytes);
@@ -518,10 +517,9 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     hipLaunchKernelGGL(iota32_kernel, dim3(256), dim3(kThreads), 0, stream, iota, T > R ? T : R);
     hipLaunchKernelGGL(ids_to_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, d.ids_a, P, R, ids32);
     if ((rc = check_launch("iota32 / ids_to_i32"))) return rc;
-    hipError_t e = hipMemsetAsync(byte0, 0, 16, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dkn_tab, 0, (size_t)R * HD * 4, stream);
-    if (e == hipSuccess) e = hipMemsetAsync(dvl_tab, 0, (size_t)R * HD * 4, stream);
-    if (e != hipSuccess) return set_error(MOT_EHIP, "cross_attn_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+    if ((rc = launch_zero_words(byte0, 4, stream))) return rc;
+    if ((rc = launch_zero_words(dkn_tab, (int64_t)R * HD, stream))) return rc;
+    if ((rc = launch_zero_words(dvl_tab, (int64_t)R * HD, stream))) return rc;
     // ---- forward recompute (the queries and the attention output come from the forward when it kept them)
     MotEmbedMixDesc g;
     if (d.saved_qy) {

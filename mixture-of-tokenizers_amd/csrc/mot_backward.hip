@@ -662,6 +662,18 @@ __device__ __forceinline__ int lower_bound_u32(const uint32_t *a, int n, uint32_
     }
     return lo;
 }
+__global__ __launch_bounds__(kThreads) void zero_i32_kernel(int32_t *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) p[i] = 0;
+}
+
+int launch_zero_words(void *p, int64_t n_words, hipStream_t stream) {
+    if (n_words <= 0) return MOT_OK;
+    int64_t blocks = (n_words + kThreads - 1) / kThreads;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, (int32_t *)p, n_words);
+    return check_launch("zero_i32_kernel");
+}
+
 template <int kRankChunk>   // positions per workgroup: 2048, or 512 when there are too few positions to fill the chip with 2048s
 __global__ __launch_bounds__(kRankThreads) void bwd_rank_kernel(const int32_t *__restrict__ tokens, int64_t n, int64_t rows,
                                                                 int32_t *__restrict__ counts, int32_t *__restrict__ rank,
@@ -852,8 +864,7 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     {
         int32_t *counts = ws_ints, *starts = counts + d.tok_rows, *rank = starts + d.tok_rows, *pos_sorted = rank + A.n_tokens,
                 *tok_sorted = pos_sorted + A.n_tokens;
-        hipError_t e = hipMemsetAsync(counts, 0, (size_t)d.tok_rows * sizeof(int32_t), stream);
-        if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+        if ((rc = launch_zero_words(counts, d.tok_rows, stream))) return rc;
         const int rank_chunk = A.n_tokens >= 256 * 2048 ? 2048 : 512;
         const int64_t rb = (A.n_tokens + rank_chunk - 1) / rank_chunk;
         int64_t pb = (A.n_tokens + kThreads - 1) / kThreads;
@@ -1407,8 +1418,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         else hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dyp, (int64_t)N * Dm, dy16);
         hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream,
                            (const __bf16 *)w16, Dm, K, wt16);
-        hipError_t e16 = hipMemsetAsync(ws16 + U.byte0, 0, 16, stream);
-        if (e16 != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e16));
+        if ((rc = launch_zero_words(ws16 + U.byte0, 4, stream))) return rc;
         if ((rc = check_launch("iota/narrow/transpose"))) return rc;
         MotEmbedMixDesc g16;
         du16_desc(g16, d, N, K);
@@ -1420,8 +1430,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     } else {
     // 3. du = dy . W through the forward MFMA kernel: "token rows" = dy (ids 0..N-1), no byte part, weight operand = W itself
     hipLaunchKernelGGL(pad_copy_kernel, dim3(512), dim3(kThreads), 0, stream, (const float *)d.weight, Dm, K, wk, L.Dmp, L.Kp);
-    hipError_t e = hipMemsetAsync(byte0, 0, 16, stream);
-    if (e != hipSuccess) return set_error(MOT_EHIP, "embed_mix_bwd: hipMemsetAsync: %s", hipGetErrorString(e));
+    if ((rc = launch_zero_words(byte0, 4, stream))) return rc;
     if ((rc = check_launch("iota/pad_copy"))) return rc;
     MotEmbedMixDesc g2;
     memset(&g2, 0, sizeof(g2));

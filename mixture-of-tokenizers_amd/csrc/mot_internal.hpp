@@ -37,6 +37,8 @@ int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hi
 // C[j][k] += sum_n A[n][j] * B[n][k]  (A: n x M, B: n x Nc; fp32 MFMA, atomic accumulate)
 int launch_gemm_tn(const float *A, int lda, int M, const float *B, int ldb, int Nc, int64_t n, float *C, int ldc, hipStream_t stream);
 int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream);
+// zero n 32-bit words with a kernel (not hipMemsetAsync: a memset node aborts on graph replay with this runtime)
+int launch_zero_words(void *p, int64_t n_words, hipStream_t stream);
 size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d);
 int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &g, hipStream_t stream);
 size_t cross_attn_workspace_bytes(const MotCrossAttnDesc &d);

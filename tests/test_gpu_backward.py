@@ -239,10 +239,41 @@ def test_grad_bucket_accumulates_in_place(mot):
         assert rel(host(a), host(p.grad)) < 2 * TOL          # two GPU results, each within TOL of the exact gradient
 
 
+def test_backward_is_capturable_in_a_hip_graph(mot):
+    """The backward enqueues a memset, the three sort kernels and the scatter kernel on the given stream, with no host
+    sync and no allocation once the workspace exists: capture it, change the batch in place, replay, compare with eager."""
+    D, Db, bpt, Vt, B, T = 256, 16, 16, 1024, 4, 300
+    Et, Eb = dev(f32(gi.normal_table(9451, Vt, D))), dev(f32(gi.normal_table(9452, gi.BYTE_VOCAB, Db)))
+    rs = np.random.RandomState(9453)
+    toks = dev(gi.fineweb_like_tokens(9454, B, T, vocab=Vt, eot_p=0.01))
+    ids = dev(rs.randint(0, gi.BYTE_VOCAB, (B, T * bpt)).astype(np.int64))
+    g = dev(f32(rs.standard_normal((B, T, D))))
+    into = {"tok_table": torch.zeros_like(Et), "byte_table": torch.zeros_like(Eb)}
+    kw = dict(mode="sum", bpt=bpt, ids_a=ids, norm_out=True, norm_byte=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        mot.functional.embed_mix_backward(g, toks, Et, Eb, into=into, **kw)     # warm-up: allocates the workspace
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        into["tok_table"].zero_(); into["byte_table"].zero_()
+        mot.functional.embed_mix_backward(g, toks, Et, Eb, into=into, **kw)
+    toks.copy_(dev(gi.fineweb_like_tokens(9455, B, T, vocab=Vt, eot_p=0.01)))
+    ids.copy_(dev(rs.randint(0, gi.BYTE_VOCAB, (B, T * bpt)).astype(np.int64)))
+    g.copy_(dev(f32(rs.standard_normal((B, T, D)))))
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = mot.functional.embed_mix_backward(g, toks, Et, Eb, **kw)
+    mot.check_status()
+    assert rel(host(into["tok_table"]), host(ref["tok_table"])) < 2 * TOL      # two GPU results (atomic order differs)
+    assert rel(host(into["byte_table"]), host(ref["byte_table"])) < 2 * TOL
+
+
 def test_sum_backward_many_chunks(mot):
-    """More positions than 256 workgroups x 2048: the lean kernel's workgroups loop over several LDS-sorted chunks, the
-    last one partial (N = 3 x 200 001 is not a multiple of anything convenient), with a tiny vocabulary so that every
-    chunk is one long run per token."""
+    """More positions than 256 workgroups x 2048, N = 3 x 200 001 not a multiple of anything convenient (partial last
+    sort chunk, uneven shares per workgroup and wave), with a tiny vocabulary: 37 long runs that cross many wave and
+    workgroup boundaries of the sorted order."""
     D, Db, bpt, Vt, B, T = 64, 8, 8, 37, 3, 200001
     rs = np.random.RandomState(9401)
     toks = rs.randint(0, Vt, (B, T)).astype(np.int32)
