@@ -311,11 +311,12 @@ def main():
                                "frac": tf / peak, "traffic": traffic,
                                "kernel": "embed_mix_linear_kernel" if args.dtype == "f32" else "embed_mix_linear_bf16_kernel",
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
-        if args.backward and mode == "sum" and args.dtype == "f32":
+        if args.backward and mode == "sum":
             from mixture_of_tokenizers_amd import data_creation as dc
             ids_b = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
             gout = torch.randn_like(out)
-            into = {"tok_table": torch.zeros_like(inp["tok_table"]), "byte_table": torch.zeros_like(inp["byte_table"])}
+            into = {"tok_table": torch.zeros_like(inp["tok_table"], dtype=torch.float32),     # gradients are fp32 for bf16 tables too
+                    "byte_table": torch.zeros_like(inp["byte_table"], dtype=torch.float32)}
             bstep = lambda: mot.functional.embed_mix_backward(gout, toks, inp["tok_table"], inp["byte_table"], mode="sum",
                                                                bpt=bpt, ids_a=ids_b, norm_out=True, into=into)
             for _ in range(3):
@@ -327,7 +328,7 @@ def main():
                 bstep()
             e1.record(); torch.cuda.synchronize()
             bms = e0.elapsed_time(e1) / nb
-            read_bytes = 2 * 4 * D * tokens_per_step   # grad_out row + token row per position (byte rows and ids come from L2)
+            read_bytes = 2 * out.element_size() * D * tokens_per_step   # grad_out row + token row per position (byte rows and ids come from L2)
             res["backward"] = {"kernel": "embed_mix_bwd_full_kernel", "kernel_ms": bms, "tokens_per_s": tokens_per_step / (bms * 1e-3),
                                "hbm_read_GBps": read_bytes / (bms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
                                "note": "whole backward call: positions grouped by token with a counting sort (bwd_rank / bwd_scan / bwd_place), "

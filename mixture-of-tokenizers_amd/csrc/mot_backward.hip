@@ -372,22 +372,35 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     float ds_t = 0.f, ds_b = 0.f;
     // element lane + 64 j of a row: ds_bpermute address of its byte slot's lane (slot * 4) and byte offset of the element
     // within a byte-table row, for 4-byte elements (x2 in the 64-bit LDS copy, /2 for bf16 tables)
+    // Register slot j of a lane holds row element lane + 64 j (fp32: one dword per lane per load), or, for bf16 rows,
+    // 2 lane + 128 (j / 2) + (j % 2): a lane loads PAIRS of adjacent bf16 as one dword (2-byte lane loads run at a
+    // fraction of the dword rate), and a pair shares its byte slot (Db is even, host-checked), so one ds_bpermute and one
+    // dword gather serve both.
+    auto elem = [&](int j) { return BF ? 2 * lane + 128 * (j >> 1) + (j & 1) : lane + 64 * j; };
     int sl4[NE], wi4[NE];
 #pragma unroll
     for (int j = 0; j < NE; ++j) {
-        const int eb = max(lane + 64 * j - A.byte_lo, 0), sl = BYTES ? eb / A.Db : 0;
+        const int eb = max(elem(j) - A.byte_lo, 0), sl = BYTES ? eb / A.Db : 0;
         sl4[j] = sl * 4;
         wi4[j] = (eb - sl * A.Db) * 4;
     }
     constexpr uint32_t esz = BF ? 2u : 4u;
-    const uint32_t loff = (uint32_t)lane * esz;   // byte offset of a lane's first element in a row
+    const uint32_t lane4 = (uint32_t)lane * 4u;   // byte offset of a lane's first dword in a row (one fp32 / two bf16 elements)
     const uint32_t row8 = (uint32_t)A.Db * 8u;
     // Rows are addressed as (wave-uniform base pointer) + (32-bit byte offset): the position and its token id are made
     // scalar with readfirstlane, so a row's 64-bit address lives in SGPRs and the per-element offsets are immediates.
-    auto ldf = [&](const void *sbase, uint32_t boff) -> float {
-        const char *q = (const char *)sbase + boff;
-        if constexpr (BF) return (float)*(const __bf16 *)q;
-        else return *(const float *)q;
+    // A row is first requested RAW (kRaw dwords per lane: one fp32 element or two bf16 each) and turned into floats later,
+    // after everything else the position needs has been requested too -- unpacking bf16 pairs right at the load makes the
+    // compiler wait for the row before it issues the byte-row gathers.
+    constexpr int kRaw = BF ? (NE + 1) / 2 : NE;   // (bf16 kernels are launched with even NE only)
+    auto load_raw = [&](const char *rbase, uint32_t (&raw)[kRaw], uint32_t mask) {   // mask: 64-element chunks present (fp32 split rows)
+#pragma unroll
+        for (int g = 0; g < kRaw; ++g) raw[g] = (BF || (mask >> g & 1)) ? *(const uint32_t *)(rbase + (lane4 + 256u * g)) : 0u;
+    };
+    auto unpack = [&](const uint32_t (&raw)[kRaw], float (&dst)[NE]) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j)
+            dst[j] = __uint_as_float(BF ? ((j & 1) ? raw[j >> 1] & 0xffff0000u : raw[j >> 1] << 16) : raw[BF ? 0 : j]);
     };
     // fixed-point scale of the privatised byte-table sums: chosen per workgroup from the upstream gradient rows of the
     // waves' first positions, v * 2^fx_k with the sample's max |g * scale_byte| at 2^27, so that a term converts through
@@ -399,9 +412,13 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     bool fx_known = !BYTES;
     auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
     auto in_range = [&](float v) { return ((__float_as_uint(v) & 0x7fffffffu) - fx_lo_bits) < fx_span; };
+    // Within its LDS row, element wi sits at wi (fp32) or, for bf16, at wi / 2 + (wi odd ? Db / 2 : 0): a lane then holds the
+    // elements 2 lane, 2 lane + 1, and with the even and the odd ones stored apart one ds_add_u64 touches consecutive
+    // 8-byte words (stride-16 addresses would double the bank conflicts).  The flush at the end undoes the permutation.
     auto add_fixed = [&](int lrow, int j, float v) {   // lrow: byte offset of the row in dbyte_q (>= 0)
         const int q = __float2int_rn(ldexpf(v, fx_k));
-        atomicAdd((unsigned long long *)((char *)dbyte_q + (uint32_t)(lrow + 2 * wi4[j])), (unsigned long long)(long long)q);
+        const int within = BF ? ((j & 1) ? wi4[j - 1] + (int)(row8 >> 1) : wi4[j]) : 2 * wi4[j];
+        atomicAdd((unsigned long long *)((char *)dbyte_q + (uint32_t)(lrow + within)), (unsigned long long)(long long)q);
     };
 
     float acc[NE], an[NE];   // the current run: gradient of the token's table row so far, its (normalised) table row
@@ -412,12 +429,12 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
         char *drow = (char *)(A.d_tok + ((int64_t)((A.abl & 32) ? 0 : cur) * A.Dt - A.tok_lo));   // abl 32: one hot row
         if (A.abl & 16) {   // abl 16: plain stores
 #pragma unroll
-            for (int j = 0; j < NE; ++j) *(float *)(drow + ((uint32_t)lane * 4u + 256u * j)) = acc[j];
+            for (int j = 0; j < NE; ++j) *(float *)(drow + (lane4 + 256u * j)) = acc[j];
             return;
         }
 #pragma unroll
         for (int j = 0; j < NE; ++j)
-            if (tmask >> j & 1) atomicAdd((float *)(drow + ((uint32_t)lane * 4u + 256u * j)), acc[j]);
+            if (tmask >> j & 1) atomicAdd((float *)(drow + (BF ? 2u * lane4 + 512u * (j >> 1) + 4u * (j & 1) : lane4 + 256u * j)), acc[j]);
     };
     auto load_id = [&](const int64_t *ids, int64_t n) {   // lanes < bpt: the token's byte ids, clamped once
         int64_t v = 0;
@@ -441,8 +458,12 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
         float gmax = 0.f;
         if (s_begin < s_end) {
             const char *grow = (const char *)A.grad_out + (int64_t)A.pos_sorted[s_begin] * D * (int64_t)esz;
+            uint32_t gr[kRaw];
+            float gs[NE];
+            load_raw(grow, gr, 0xffffffffu);
+            unpack(gr, gs);
 #pragma unroll
-            for (int j = 0; j < NE; ++j) gmax = fmaxf(gmax, fabsf(ldf(grow, loff + 64u * esz * j)));
+            for (int j = 0; j < NE; ++j) gmax = fmaxf(gmax, fabsf(gs[j]));
             gmax = wave_max(gmax) * fabsf(s_byte);
             if (lane == 0 && gmax > 0.f && gmax < INFINITY) atomicMax(fx_bits, __float_as_uint(gmax));
         }
@@ -472,48 +493,130 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
             float bn[NE], dy[NE];
             int lra[NE], lrb[NE];   // byte offset of the element's row in the LDS copy (negative: no slot), first / second id tensor
             const char *grow = (const char *)A.grad_out + n * D * (int64_t)esz;
+            // The two element types get their own copy of the request / gather part: the bf16 one keeps raw dwords until
+            // everything is in flight; folding both into one body cost the fp32 kernel 5 % (scheduling, not instruction count).
+            if constexpr (BF) {
+                uint32_t graw[kRaw], traw[kRaw], braw[kRaw], braw2[kRaw];
+                load_raw(grow, graw, 0xffffffffu);
+                if constexpr (!BF) unpack(graw, dy);
+                const bool newrun = tok != cur;   // the previous token's gradient row leaves, this token's row comes in
+                auto begin_run = [&]() {   // raw token row -> floats, its gradient accumulator, its rms factor
+                    unpack(traw, an);
 #pragma unroll
-            for (int j = 0; j < NE; ++j) dy[j] = ldf(grow, loff + 64u * esz * j);
-            if (tok != cur) {   // a new run: the previous token's gradient row leaves, this token's (normalised) row comes in
-                flush();
-                cur = tok;
-                const char *trow = (const char *)A.tok_table + ((int64_t)tok * A.Dt - A.tok_lo) * (int64_t)esz;
+                    for (int j = 0; j < NE; ++j) acc[j] = 0.f;
+                    ra = 1.f;
+                    if (A.norm_tok) {
+                        float ss = 0.f;
 #pragma unroll
-                for (int j = 0; j < NE; ++j) {
-                    acc[j] = 0.f;
-                    an[j] = (tmask >> j & 1) ? ldf(trow, loff + 64u * esz * j) : 0.f;
-                }
-                ra = 1.f;
-                if (A.norm_tok) {
-                    float ss = 0.f;
+                        for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
+                        ra = rms_scale(wave_sum(ss), A.Dt, A.eps);
 #pragma unroll
-                    for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
-                    ra = rms_scale(wave_sum(ss), A.Dt, A.eps);
-#pragma unroll
-                    for (int j = 0; j < NE; ++j) an[j] *= ra;
-                }
-            }
-            if (BYTES) {
-                // lanes < bpt: gather offset of the slot's byte row and offset of its LDS row (or -1)
-                const int ga = ida * A.Db * (int)esz, gb = idb * A.Db * (int)esz;
-                const int sa = byte_slot(ida), sb = byte_slot(idb);
-                const int la = sa >= 0 ? sa * (int)row8 : -1, lb = sb >= 0 ? sb * (int)row8 : -1;
-#pragma unroll
-                for (int j = 0; j < NE; ++j) {
-                    bn[j] = 0.f; lra[j] = 0; lrb[j] = 0;
-                    if (!(bmask >> j & 1)) continue;
-                    const uint32_t w = BF ? (uint32_t)wi4[j] >> 1 : (uint32_t)wi4[j];
-                    float v = ldf(A.byte_table, (uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], ga) + w);
-                    lra[j] = __builtin_amdgcn_ds_bpermute(sl4[j], la);
-                    if (dual) {
-                        v += ldf(A.byte_table, (uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], gb) + w);
-                        lrb[j] = __builtin_amdgcn_ds_bpermute(sl4[j], lb);
+                        for (int j = 0; j < NE; ++j) an[j] *= ra;
                     }
-                    bn[j] = v;
+                };
+                if (newrun) {
+                    flush();
+                    cur = tok;
+                    load_raw((const char *)A.tok_table + ((int64_t)tok * A.Dt - A.tok_lo) * (int64_t)esz, traw, tmask);
+                    if constexpr (!BF) begin_run();   // fp32: nothing to unpack, the compiler places the waits at the first use
                 }
-                if (more) {   // the next position's byte ids while this one's rows are in flight
-                    ida_nx = load_id(A.ids_a, n_nx);
-                    if (dual) idb_nx = load_id(A.ids_b, n_nx);
+                if (BYTES) {
+                    // lanes < bpt: gather offset of the slot's byte row and offset of its LDS row (or -1)
+                    const int ga = ida * A.Db * (int)esz, gb = idb * A.Db * (int)esz;
+                    const int sa = byte_slot(ida), sb = byte_slot(idb);
+                    const int la = sa >= 0 ? sa * (int)row8 : -1, lb = sb >= 0 ? sb * (int)row8 : -1;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        if (BF && (j & 1)) continue;   // a bf16 pair (j, j + 1) lies in one byte row: one permute, one dword gather
+                        lra[j] = 0; lrb[j] = 0;
+                        if constexpr (BF) {
+                            const int g = j >> 1;
+                            braw[g] = 0u; braw2[g] = 0u;
+                            if (bmask >> j & 1) {
+                                const uint32_t w = (uint32_t)wi4[j] >> 1;
+                                braw[g] = *(const uint32_t *)((const char *)A.byte_table + ((uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], ga) + w));
+                                lra[j] = __builtin_amdgcn_ds_bpermute(sl4[j], la);
+                                if (dual) {
+                                    braw2[g] = *(const uint32_t *)((const char *)A.byte_table + ((uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], gb) + w));
+                                    lrb[j] = __builtin_amdgcn_ds_bpermute(sl4[j], lb);
+                                }
+                            }
+                            if (j + 1 < NE) { lra[j + 1] = lra[j]; lrb[j + 1] = lrb[j]; }
+                        } else {
+                            bn[j] = 0.f;
+                            if (!(bmask >> j & 1)) continue;
+                            const uint32_t w = (uint32_t)wi4[j];
+                            float v = *(const float *)((const char *)A.byte_table + ((uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], ga) + w));
+                            lra[j] = __builtin_amdgcn_ds_bpermute(sl4[j], la);
+                            if (dual) {
+                                v += *(const float *)((const char *)A.byte_table + ((uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], gb) + w));
+                                lrb[j] = __builtin_amdgcn_ds_bpermute(sl4[j], lb);
+                            }
+                            bn[j] = v;
+                        }
+                    }
+                    if (more) {   // the next position's byte ids while this one's rows are in flight
+                        ida_nx = load_id(A.ids_a, n_nx);
+                        if (dual) idb_nx = load_id(A.ids_b, n_nx);
+                    }
+                }
+                if constexpr (BF) {   // everything is requested: raw words -> floats
+                    unpack(graw, dy);
+                    if (BYTES) {
+                        unpack(braw, bn);
+                        if (dual) {
+                            float b2[NE];
+                            unpack(braw2, b2);
+#pragma unroll
+                            for (int j = 0; j < NE; ++j) bn[j] += b2[j];
+                        }
+                    }
+                    if (newrun) begin_run();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) dy[j] = *(const float *)(grow + (lane4 + 256u * j));
+                if (tok != cur) {   // a new run: the previous token's gradient row leaves, this token's (normalised) row comes in
+                    flush();
+                    cur = tok;
+                    const char *trow = (const char *)A.tok_table + ((int64_t)tok * A.Dt - A.tok_lo) * (int64_t)esz;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        acc[j] = 0.f;
+                        an[j] = (tmask >> j & 1) ? *(const float *)(trow + (lane4 + 256u * j)) : 0.f;
+                    }
+                    ra = 1.f;
+                    if (A.norm_tok) {
+                        float ss = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
+                        ra = rms_scale(wave_sum(ss), A.Dt, A.eps);
+#pragma unroll
+                        for (int j = 0; j < NE; ++j) an[j] *= ra;
+                    }
+                }
+                if (BYTES) {
+                    // lanes < bpt: gather offset of the slot's byte row and offset of its LDS row (or -1)
+                    const int ga = ida * A.Db * (int)esz, gb = idb * A.Db * (int)esz;
+                    const int sa = byte_slot(ida), sb = byte_slot(idb);
+                    const int la = sa >= 0 ? sa * (int)row8 : -1, lb = sb >= 0 ? sb * (int)row8 : -1;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        bn[j] = 0.f; lra[j] = 0; lrb[j] = 0;
+                        if (!(bmask >> j & 1)) continue;
+                        const uint32_t w = (uint32_t)wi4[j];
+                        float v = *(const float *)((const char *)A.byte_table + ((uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], ga) + w));
+                        lra[j] = __builtin_amdgcn_ds_bpermute(sl4[j], la);
+                        if (dual) {
+                            v += *(const float *)((const char *)A.byte_table + ((uint32_t)__builtin_amdgcn_ds_bpermute(sl4[j], gb) + w));
+                            lrb[j] = __builtin_amdgcn_ds_bpermute(sl4[j], lb);
+                        }
+                        bn[j] = v;
+                    }
+                    if (more) {   // the next position's byte ids while this one's rows are in flight
+                        ida_nx = load_id(A.ids_a, n_nx);
+                        if (dual) idb_nx = load_id(A.ids_b, n_nx);
+                    }
                 }
             }
             float rnb = 1.f;   // lanes < bpt: 1/rms of the slot's byte row
@@ -641,7 +744,8 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
         for (int i = tid; i < nbyte; i += kBwdThreads) {
             const long long q = (long long)dbyte_q[i];
             if (q == 0) continue;
-            const int sl = i / A.Db, wi = i - sl * A.Db;
+            const int sl = i / A.Db, at = i - sl * A.Db, half = A.Db >> 1;
+            const int wi = BF ? (at < half ? 2 * at : 2 * (at - half) + 1) : at;
             const int row = sl < A.priv_lo ? sl : sl - A.priv_lo + A.priv_hi0;
             atomicAdd(A.d_byte + row * A.Db + wi, (float)ldexp((double)q, -fx_k));
         }
@@ -810,6 +914,7 @@ static bool full_layout(const BwdArgs &A) {
     } else {
         if (A.Dt != A.D || A.tok_lo != 0) return false;
         if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D || A.Db > 0xffff)) return false;
+        if (A.in_bf16 && ((A.D & 127) || (MODE == MOT_MIX_SUM && (A.Db & 1)))) return false;   // bf16 rows are read as pairs
     }
     if (A.abl & 4) return false;   // abl 4: dev switch back to the general kernel
     const int ne = A.D / 64;
