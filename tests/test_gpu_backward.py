@@ -239,6 +239,24 @@ def test_grad_bucket_accumulates_in_place(mot):
         assert rel(host(a), host(p.grad)) < 2 * TOL          # two GPU results, each within TOL of the exact gradient
 
 
+@pytest.mark.parametrize("B,T,Vt,same", [(1, 1, 5, False), (1, 67, 3, True), (5, 413, 1, True), (3, 1000, 50000, False)])
+def test_sum_backward_degenerate_groupings(mot, B, T, Vt, same):
+    """The counting sort's corner cases: a single position, every position the same token (one run that crosses every
+    wave and workgroup boundary), a one-row table, and a vocabulary far larger than the batch (almost no reuse)."""
+    D, Db, bpt = 128, 16, 8
+    rs = np.random.RandomState(9470 + T)
+    toks = (np.full((B, T), Vt - 1) if same else rs.randint(0, Vt, (B, T))).astype(np.int32)
+    ids = rs.randint(0, gi.BYTE_VOCAB, (B, T * bpt)).astype(np.int64)
+    Et, Eb = f32(gi.normal_table(9471, Vt, D)), f32(gi.normal_table(9472, gi.BYTE_VOCAB, Db))
+    g = f32(rs.standard_normal((B, T, D)))
+    kw = dict(mode="sum", bpt=bpt, norm_out=True, norm_tok=True)
+    ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), dtype=np.float64, **kw)
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), ids_a=dev(ids), **kw)
+    mot.check_status()
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+    assert rel(host(got["byte_table"]), ref["byte_table"]) < TOL
+
+
 def test_backward_is_capturable_in_a_hip_graph(mot):
     """The backward enqueues a memset, the three sort kernels and the scatter kernel on the given stream, with no host
     sync and no allocation once the workspace exists: capture it, change the batch in place, replay, compare with eager."""
