@@ -200,8 +200,13 @@ def main():
     elif mode == "concat_linear":
         tab = torch.from_numpy(inp["tab"]).to(device)
 
-        kwf = dict(mode="concat_linear", bpt=bpt, ttb=tab, pull="left", weight=inp["weight"], norm_tok=True, norm_byte=True,
-                   norm_out=True, out=out)
+        if args.ids == "fused":
+            kwf = dict(mode="concat_linear", bpt=bpt, ttb=tab, pull="left", weight=inp["weight"], norm_tok=True, norm_byte=True,
+                       norm_out=True, out=out)
+        else:   # the module seam: byte ids precomputed as the reference's loader emits them
+            from mixture_of_tokenizers_amd import data_creation as dc
+            ids = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
+            kwf = dict(mode="concat_linear", bpt=bpt, ids_a=ids, weight=inp["weight"], norm_tok=True, norm_byte=True, norm_out=True, out=out)
     else:
         chars = torch.from_numpy(inp["chars"]).to(device)
         lt, lc = torch.tensor(1.0, device=device), torch.tensor(0.5, device=device)
@@ -309,7 +314,9 @@ def main():
             peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
             res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                                "frac": tf / peak, "traffic": traffic,
-                               "kernel": "embed_mix_linear_kernel" if args.dtype == "f32" else "embed_mix_linear_bf16_kernel",
+                               "kernel": ("embed_mix_linear_bf16_kernel" if args.dtype != "f32" else
+                                          "embed_mix_linear_kernel" if args.ids == "fused" else
+                                          "gather_rows_kernel x2 + gemm_rows_kernel + rows_rms_inplace_kernel (whole call)"),
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
         if args.backward and mode == "sum":
             from mixture_of_tokenizers_amd import data_creation as dc

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kThreads) void iota32_kernel(int32_t *p, int64_t n)
 
 // ------------------------------------------------------------------------------------------ host
 // workspace, in floats: [q: T*HD][y: T*HD][kt: R*HD][vt: R*HD][xkv: dual ? T*bpt*D : 0][iota: max(T, R) int32][byte0: 4][lin: ...]
-struct AttnLayout { size_t q, y, kt, vt, xkv, iota, byte0, lin, lin_floats, total; int64_t R; };
+struct AttnLayout { size_t q, y, kt, vt, xkv, xq, iota, byte0, lin, lin_floats, total; int64_t R; };
 
 static void dense_desc(MotEmbedMixDesc &g, const int32_t *iota, const float *byte0, const void *rows, int64_t n_rows_tab, int64_t n, int K,
                        const void *weight, int Dm, void *out, uint32_t *status, void *ws, size_t ws_bytes) {
@@ -165,6 +165,7 @@ static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
     L.q = take(T * HD); L.y = take(T * HD); L.kt = take((size_t)L.R * HD); L.vt = take((size_t)L.R * HD);
     L.xkv = take(dual ? T * d.bpt * D : 0);
+    L.xq = take(D > HD ? T * D : 0);   // the gathered query rows live in y's place until the attention writes y
     L.iota = take(T > (size_t)L.R ? T : (size_t)L.R); L.byte0 = take(4);
     MotEmbedMixDesc g;     // the widest of the GEMMs decides the transposed-weight scratch
     const int64_t max_rows = d.tok_rows > L.R ? d.tok_rows : L.R;   // the normalising GEMMs keep a per-row rms table in the scratch
@@ -209,10 +210,11 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     if ((rc = check_launch("iota32_kernel"))) return rc;
     if ((rc = launch_zero_words(byte0, 4, stream))) return rc;
     MotEmbedMixDesc g;
-    // 1. q = W_q norm?(E_t[tok])          (train_gpt.py:348-377 + 277)
-    dense_desc(g, d.tokens, byte0, d.tok_table, d.tok_rows, T, D, d.q_w, HD, q, d.status, lin, lin_bytes);
-    g.norm_tok = d.norm_tok; g.eps = eps;
-    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+    // 1. q = W_q norm?(E_t[tok])          (train_gpt.py:348-377 + 277): seam gather, then the plain dense MFMA kernel
+    float *xq = D > HD ? ws + L.xq : y;
+    if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, (int)D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
+        return rc;
+    if ((rc = launch_gemm_rows(xq, (int)D, T, (const float *)d.q_w, (int)D, (int)D, (int)HD, q, (int)HD, true, stream))) return rc;
     // 2. key/value rows: per byte-table row, or per kv position when the embedding is norm(E[a] + E[b])
     const void *kv_rows = d.byte_table;
     int kv_norm = d.norm_byte;
@@ -242,9 +244,8 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     const int64_t waves = T * H;
     hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
     if ((rc = check_launch("cross_attn_kernel"))) return rc;
-    // 4. out = c_proj y                   (line 293)
-    dense_desc(g, iota, byte0, y, T, T, HD, d.proj_w, D, d.out, d.status, lin, lin_bytes);
-    return launch_embed_mix_linear(g, stream);
+    // 4. out = c_proj y                   (line 293): out[t][c] = sum_r y[t][r] * proj_w[c][r]
+    return launch_gemm_rows(y, (int)HD, T, (const float *)d.proj_w, (int)HD, (int)HD, (int)D, (float *)d.out, (int)D, true, stream);
 }
 
 
@@ -487,15 +488,11 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
 
 size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d) { return attn_bwd_layout(d).total * 4; }
 
-// out[n][Nout] = rows[n][Kc] . W[Kc][Nout]  (W k-major, unpadded) through the forward MFMA kernel in dense-row mode
+// out[n][Nout] = rows[n][Kc] . W[Kc][Nout]  (W k-major, unpadded): the plain dense MFMA kernel
 static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *W, int Nout, float *out, float *wk, const int32_t *iota, const float *byte0,
                              uint32_t *status, hipStream_t stream) {
-    const int kp = (Kc + 15) / 16 * 16, np = out_cols_pad(Nout);
-    int rc;
-    if ((rc = launch_pad_copy(W, Kc, Nout, wk, kp, np, stream))) return rc;
-    MotEmbedMixDesc g;
-    dense_desc(g, iota, byte0, rows, n, n, Kc, nullptr, Nout, out, status, nullptr, 0);
-    return launch_embed_mix_linear_ex(g, wk, np, stream);
+    (void)wk; (void)iota; (void)byte0; (void)status;
+    return launch_gemm_rows(rows, Kc, n, W, Nout, Kc, Nout, out, Nout, false, stream);
 }
 
 int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr, hipStream_t stream) {
@@ -522,13 +519,14 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     if ((rc = launch_zero_words(dvl_tab, (int64_t)R * HD, stream))) return rc;
     // ---- forward recompute (the queries and the attention output come from the forward when it kept them)
     MotEmbedMixDesc g;
+    bool have_xq = false;   // the gathered (normalised) token rows are already in xq
     if (d.saved_qy) {
         q = (float *)d.saved_qy;
         y = q + (size_t)T * HD;
     } else {
-        dense_desc(g, d.tokens, byte0, d.tok_table, d.tok_rows, T, D, d.q_w, HD, q, d.status, lin, lin_bytes);
-        g.norm_tok = d.norm_tok; g.eps = eps;
-        if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+        if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream))) return rc;
+        if ((rc = launch_gemm_rows(xq, D, T, (const float *)d.q_w, D, D, HD, q, HD, true, stream))) return rc;
+        have_xq = true;
     }
     const float *kv_w = (const float *)d.kv_w;
     dense_desc(g, iota, byte0, d.byte_table, R, R, D, kv_w, HD, kpre, d.status, lin, lin_bytes);
@@ -584,7 +582,8 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     }
     // ---- q_w and the token table
     if (gr.d_q_w) {
-        if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream))) return rc;
+        if (!have_xq && (rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
+            return rc;
         if ((rc = launch_gemm_tn(dq, HD, HD, xq, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
     }
     if (gr.d_tok_table) {

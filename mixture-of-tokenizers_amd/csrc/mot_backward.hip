@@ -1191,6 +1191,142 @@ int launch_gemm_tn(const float *A_, int lda, int M, const float *B_, int ldb, in
     return check_launch("gemm_tn_kernel");
 }
 
+// C[n][c] = sum_r A[n][r] * (BT ? B[c][r] : B[r][c])   (A: n x R rows, C: n x Nc; leading dimensions lda / ldb / ldc), fp32 MFMA.
+// Same block shape and inner loop as gemm_tn_kernel -- 128 x 128 output block, 16 reduction indices per step, both operands in
+// LDS as [reduction index][block row / column], one conflict-free ds_read_b32 per MFMA operand -- with the operand whose rows
+// are contiguous along r (A always, B when BT) transposed on its way into LDS: a lane takes 4 consecutive r of ONE row and
+// the 64 lanes of a wave take 64 consecutive rows, so the four ds_write_b32 hit consecutive banks.  The reduction is whole
+// inside the workgroup (plain stores).  The fused gather + norm kernel (mot_linear.hip) runs its dense-row mode at 48 % of
+// the fp32 MFMA peak; this loop reaches ~75 %.
+template <bool BT>
+__global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb,
+                                                             int R, int Nc, float *__restrict__ C, int ldc, const float *__restrict__ bias,
+                                                             int accumulate) {
+    __shared__ __attribute__((aligned(16))) float lA[2][16 * 128], lB[2][16 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
+    const int64_t j0 = (int64_t)blockIdx.x * 128;
+    const int k0 = blockIdx.y * 128;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16b acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool va = (lda & 3) == 0 && ((uintptr_t)A_ & 15) == 0, vb = (ldb & 3) == 0 && ((uintptr_t)B_ & 15) == 0;
+    float4v ra[2], rb[2];
+    // rows-contiguous-along-r operand: thread -> (row = q & 127, 4 consecutive r starting at (q >> 7) * 4)
+    auto load_t = [&](const float *P, int ld, int64_t row0, int64_t rows, bool vec, int r, float4v (&dst)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + tid, row = q & 127, c4 = (q >> 7) * 4;
+            dst[p] = (float4v)(0.f);
+            if (row0 + row < rows) {
+                const float *src = P + (row0 + row) * ld + r + c4;
+                if (vec && r + c4 + 3 < R) dst[p] = *(const float4v *)src;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (r + c4 + e < R) dst[p][e] = src[e];
+            }
+        }
+    };
+    auto store_t = [&](float *L, const float4v (&srcv)[2]) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kThreads + tid, row = q & 127, c4 = (q >> 7) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) L[(c4 + e) * 128 + row] = srcv[p][e];
+        }
+    };
+    auto load_stage = [&](int r) {
+        load_t(A_, lda, j0, n, va, r, ra);
+        if (BT) {
+            load_t(B_, ldb, k0, Nc, vb, r, rb);
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {   // natural layout: 16 reduction rows x 32 float4
+                const int q = p * kThreads + tid, row = q >> 5, c4 = (q & 31) * 4;
+                rb[p] = (float4v)(0.f);
+                if (r + row < R) {
+                    const float *src = B_ + (int64_t)(r + row) * ldb + k0 + c4;
+                    if (vb && k0 + c4 + 3 < Nc) rb[p] = *(const float4v *)src;
+                    else
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (k0 + c4 + e < Nc) rb[p][e] = src[e];
+                }
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+        store_t(lA[buf], ra);
+        if (BT) store_t(lB[buf], rb);
+        else
+#pragma unroll
+            for (int p = 0; p < 2; ++p) *(float4v *)(&lB[buf][(p * kThreads + tid) * 4]) = rb[p];
+    };
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int r = 0; r < R; r += 16, buf ^= 1) {
+        const bool more = r + 16 < R;
+        if (more) load_stage(r + 16);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float a0 = lA[buf][(kk + h) * 128 + wm + li], a1 = lA[buf][(kk + h) * 128 + wm + 32 + li];
+            const float b0 = lB[buf][(kk + h) * 128 + wn + li], b1 = lB[buf][(kk + h) * 128 + wn + 32 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t j = j0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int k = k0 + wn + b * 32 + li;
+                if (j < n && k < Nc) {
+                    float v = acc[a][b][r];
+                    if (bias) v += bias[k];
+                    if (accumulate) v += C[j * ldc + k];
+                    C[j * ldc + k] = v;
+                }
+            }
+}
+
+// The reduction is cut into launches of at most kGemmRowsPass indices, the later ones adding to C: one fp32 MFMA summation
+// chain over K = 1024 ends up 2.1x as far from the float64 result as the reference's blocked CPU sgemm (the parity bar is
+// 2x); a second accumulator set inside the kernel would halve its occupancy and cost 10 %.
+constexpr int kGemmRowsPass = 768;
+int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed,
+                     hipStream_t stream, const float *bias) {
+    if (n <= 0 || Nc <= 0) return MOT_OK;
+    const int64_t gx = (n + 127) / 128;
+    const int gy = (Nc + 127) / 128;
+    if (gx > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows: too many rows");
+    for (int r0 = 0; r0 < R || r0 == 0; r0 += kGemmRowsPass) {
+        const int rn = R - r0 < kGemmRowsPass ? R - r0 : kGemmRowsPass;
+        const float *a = A_ + r0, *b = b_transposed ? B_ + r0 : B_ + (int64_t)r0 * ldb;
+        if (b_transposed)
+            hipLaunchKernelGGL(gemm_rows_kernel<true>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
+                               r0 ? nullptr : bias, r0 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(gemm_rows_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
+                               r0 ? nullptr : bias, r0 ? 1 : 0);
+        if (r0 + kGemmRowsPass >= R) break;
+    }
+    return check_launch("gemm_rows_kernel");
+}
+
 // workspace of the CONCAT backward, in floats unless noted:
 //   [rnorm: byte_rows][dy: N*Dm][du: N*K][u_tok: N*Dt][u_byte: N*bpt*Db][Wk: Dm16*K128][byte0: 4][iota: N int32][zero ids: 0]
 //   [sort ints: 3*tok_rows + N]
@@ -1460,6 +1596,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     float *ws = (float *)d.workspace;
     float *rn = ws + L.rnorm, *dy = ws + L.dy, *du = ws + L.du, *utok = ws + L.utok, *ubyte = ws + L.ubyte, *wk = ws + L.wk, *byte0 = ws + L.byte0;
     int32_t *iota = (int32_t *)(ws + L.iota), *sort_ints = (int32_t *)(ws + L.sort);
+    (void)wk; (void)byte0;   // slots of the layout the fp32 du product no longer uses
     const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
     int rc;
     // 1. dy
@@ -1533,18 +1670,8 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         if ((rc = launch_embed_mix_linear_bf16(g16, stream))) return rc;
         if ((rc = launch_widen(du16, (size_t)N * K, du, stream))) return rc;
     } else {
-    // 3. du = dy . W through the forward MFMA kernel: "token rows" = dy (ids 0..N-1), no byte part, weight operand = W itself
-    hipLaunchKernelGGL(pad_copy_kernel, dim3(512), dim3(kThreads), 0, stream, (const float *)d.weight, Dm, K, wk, L.Dmp, L.Kp);
-    if ((rc = launch_zero_words(byte0, 4, stream))) return rc;
-    if ((rc = check_launch("iota/pad_copy"))) return rc;
-    MotEmbedMixDesc g2;
-    memset(&g2, 0, sizeof(g2));
-    g2.struct_size = sizeof(g2); g2.dtype = MOT_F32;
-    g2.n_rows = 1; g2.tokens_per_row = N; g2.bpt = 0; g2.mode = MOT_MIX_CONCAT_LINEAR;
-    g2.tokens = iota; g2.id_source = MOT_IDS_GIVEN; g2.ids_a = (const int64_t *)iota;  // never read with bpt == 0
-    g2.tok_table = dyp; g2.tok_rows = N; g2.tok_dim = Dm; g2.byte_table = byte0; g2.byte_rows = 1; g2.byte_dim = 4;
-    g2.model_dim = K; g2.out = du; g2.status = d.status;
-    if ((rc = launch_embed_mix_linear_ex(g2, wk, L.Kp, stream))) return rc;
+    // 3. du = dy . W   (N x Dm) @ (Dm x K): both row-major as they are (nn.Linear keeps W as [Dm][K])
+    if ((rc = launch_gemm_rows(dyp, Dm, N, (const float *)d.weight, K, Dm, K, du, K, false, stream))) return rc;
     }
     // 4. table gradients from du (its row layout is the concat layout)
     BwdArgs A;

@@ -192,7 +192,10 @@ template <int G, typename IdT, typename T>
 __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const IdT *__restrict__ ids_a, const IdT *__restrict__ ids_b,
                                                                int64_t n, const T *__restrict__ table, int64_t rows,
                                                                int dim, int rms, float eps, const float *scale,
-                                                               T *__restrict__ out, uint32_t *status) {
+                                                               T *__restrict__ out, uint32_t *status, int group, int64_t out_ld,
+                                                               uint32_t oor_flag) {
+    // row r lands at out + (r / group) * out_ld + (r % group) * dim: group 1, out_ld dim = a dense [n, dim] tensor;
+    // group bpt, out_ld K = the byte part of the concat operand [tokens, K]
     const int g = threadIdx.x % G;
     const int64_t per_block = kThreads / G;
     const float s = scale ? *scale : 1.0f;
@@ -200,12 +203,12 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const IdT *__rest
     for (int64_t r = (int64_t)blockIdx.x * per_block + threadIdx.x / G; r < n; r += (int64_t)gridDim.x * per_block) {
         int64_t ia = (int64_t)ids_a[r], ib = ids_b ? (int64_t)ids_b[r] : 0;
         if ((uint64_t)ia >= (uint64_t)rows || (uint64_t)ib >= (uint64_t)rows) {
-            if (status) atomicOr(status, kStatusByteOor);
+            if (status) atomicOr(status, oor_flag);
             if ((uint64_t)ia >= (uint64_t)rows) ia = 0;
             if ((uint64_t)ib >= (uint64_t)rows) ib = 0;
         }
         const T *pa = table + ia * dim, *pb = table + ib * dim;
-        T *po = out + r * dim;
+        T *po = group == 1 ? out + r * out_ld : out + (r / group) * out_ld + (r % group) * dim;
         float mult = s;
         if (rms) {
             float ss = 0.f;
@@ -250,36 +253,45 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const IdT *__rest
 template <int G, typename T>
 static int launch_gather_g(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table,
                            int64_t rows, int dim, int rms, float eps, const float *scale, void *out, uint32_t *status,
-                           hipStream_t stream) {
+                           int group, int64_t out_ld, uint32_t oor_flag, hipStream_t stream) {
     const int64_t per_block = kThreads / G;
     int64_t blocks = (n + per_block - 1) / per_block;
     if (blocks > 256 * 16) blocks = 256 * 16;
     if (ids_elem == 8)
         hipLaunchKernelGGL((gather_rows_kernel<G, int64_t, T>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
-                           (const int64_t *)ids_a, (const int64_t *)ids_b, n, (const T *)table, rows, dim, rms, eps, scale, (T *)out, status);
+                           (const int64_t *)ids_a, (const int64_t *)ids_b, n, (const T *)table, rows, dim, rms, eps, scale, (T *)out, status, group, out_ld, oor_flag);
     else
         hipLaunchKernelGGL((gather_rows_kernel<G, int32_t, T>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
-                           (const int32_t *)ids_a, (const int32_t *)ids_b, n, (const T *)table, rows, dim, rms, eps, scale, (T *)out, status);
+                           (const int32_t *)ids_a, (const int32_t *)ids_b, n, (const T *)table, rows, dim, rms, eps, scale, (T *)out, status, group, out_ld, oor_flag);
     return check_launch("gather_rows_kernel");
 }
 
 template <typename T>
 static int launch_gather_t(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
-                           int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, hipStream_t stream) {
+                           int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int group, int64_t out_ld,
+                           uint32_t oor_flag, hipStream_t stream) {
     const int lanes = (dim & 3) == 0 ? dim / 4 : dim;
-    if (lanes <= 8) return launch_gather_g<8, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
-    if (lanes <= 16) return launch_gather_g<16, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
-    if (lanes <= 32) return launch_gather_g<32, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
-    return launch_gather_g<64, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    if (lanes <= 8) return launch_gather_g<8, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, group, out_ld, oor_flag, stream);
+    if (lanes <= 16) return launch_gather_g<16, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, group, out_ld, oor_flag, stream);
+    if (lanes <= 32) return launch_gather_g<32, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, group, out_ld, oor_flag, stream);
+    return launch_gather_g<64, T>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, group, out_ld, oor_flag, stream);
+}
+
+int launch_gather_rows_placed(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
+                              int dim, int rms_norm, float eps, const float *scale, void *out, int group, int64_t out_ld,
+                              uint32_t *status, uint32_t oor_flag, int dtype, hipStream_t stream) {
+    if (n == 0) return MOT_OK;
+    if (eps <= 0.f) eps = dtype == MOT_BF16 ? 0.0078125f : FLT_EPSILON;
+    if (dtype == MOT_BF16)
+        return launch_gather_t<__bf16>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, group, out_ld, oor_flag, stream);
+    return launch_gather_t<float>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, group, out_ld, oor_flag, stream);
 }
 
 int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
                        int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int dtype,
                        hipStream_t stream) {
-    if (n == 0) return MOT_OK;
-    if (eps <= 0.f) eps = dtype == MOT_BF16 ? 0.0078125f : FLT_EPSILON;
-    if (dtype == MOT_BF16) return launch_gather_t<__bf16>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
-    return launch_gather_t<float>(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, status, stream);
+    return launch_gather_rows_placed(ids_a, ids_b, ids_elem, n, table, rows, dim, rms_norm, eps, scale, out, 1, dim, status, kStatusByteOor, dtype,
+                                     stream);
 }
 
 int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float *out, int dtype, hipStream_t stream) {

@@ -24,6 +24,10 @@ int launch_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void 
 int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
                        int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int dtype,
                        hipStream_t stream);
+// the same gather with row r written at out + (r / group) * out_ld + (r % group) * dim, and the status bit to raise
+int launch_gather_rows_placed(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
+                              int dim, int rms_norm, float eps, const float *scale, void *out, int group, int64_t out_ld,
+                              uint32_t *status, uint32_t oor_flag, int dtype, hipStream_t stream);
 int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float *out, int dtype, hipStream_t stream);
 size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream);         // SUM / MEAN / NOOP
@@ -36,6 +40,9 @@ size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hipStream_t stream);
 // C[j][k] += sum_n A[n][j] * B[n][k]  (A: n x M, B: n x Nc; fp32 MFMA, atomic accumulate)
 int launch_gemm_tn(const float *A, int lda, int M, const float *B, int ldb, int Nc, int64_t n, float *C, int ldc, hipStream_t stream);
+// C[n][c] = sum_r A[n][r] * (b_transposed ? B[c][r] : B[r][c]) (+ bias[c]), fp32 MFMA, plain stores
+int launch_gemm_rows(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed, hipStream_t stream,
+                     const float *bias = nullptr);
 int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream);
 // zero n 32-bit words with a kernel (not hipMemsetAsync: a memset node aborts on graph replay with this runtime)
 int launch_zero_words(void *p, int64_t n_words, hipStream_t stream);

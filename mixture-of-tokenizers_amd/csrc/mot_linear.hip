@@ -350,7 +350,65 @@ static int nt_of(int Dm) {
     return -1;
 }
 
+// ------------------------------------------------------------------------------------------ composed path (ids given)
+// With the byte ids already in HBM (the module seam: FlexibleEmbedding hands them over as the reference's loader made
+// them) the forward is composed from three plain kernels: the seam gather writes the normalised concat operand u
+// [tokens, K] (token part and byte part placed side by side), gemm_rows_kernel contracts it with W at ~68 % of the fp32
+// MFMA peak (the fused tile kernel below reaches 48 %), and a row pass applies the output norm.  u costs two extra passes
+// over tokens x K floats, which the faster contraction more than pays for; it is built in slabs of kSlabRows rows so the
+// scratch stays bounded.  The fused kernel remains the path for ids pulled in-kernel from the token->byte table.
+constexpr int64_t kSlabRows = 65536;
+static bool composed_path(const MotEmbedMixDesc &d) {
+    static const bool off = getenv("MOT_LIN_FUSED") != nullptr;   // dev / A-B switch: always the fused tile kernel
+    return !off && d.id_source == MOT_IDS_GIVEN && d.bpt > 0 && !d.scale_tok && !d.scale_byte;
+}
+static size_t composed_floats(const MotEmbedMixDesc &d) {
+    const int64_t n = d.n_rows * d.tokens_per_row;
+    return (size_t)(n < kSlabRows ? n : kSlabRows) * (size_t)(d.tok_dim + d.bpt * d.byte_dim);
+}
+
+// x[r] *= rsqrt(mean(x[r]^2) + eps) in place, one wave per row; the factor is kept for the backward
+__global__ __launch_bounds__(kThreads) void rows_rms_inplace_kernel(float *__restrict__ x, int64_t n, int dim, float eps, float *__restrict__ row_rnorm) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= n) return;
+    float *p = x + r * dim;
+    float ss = 0.f;
+    for (int j = lane; j < dim; j += 64) ss += p[j] * p[j];
+    const float rs = rms_scale(wave_sum(ss), dim, eps);
+    for (int j = lane; j < dim; j += 64) p[j] *= rs;
+    if (row_rnorm && lane == 0) row_rnorm[r] = rs;
+}
+
+static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
+    const int64_t N = d.n_rows * d.tokens_per_row;
+    const int Dt = d.tok_dim, Db = d.byte_dim, bpt = d.bpt, K = Dt + bpt * Db, Dm = d.model_dim;
+    const int tok_lo = d.bytes_first ? bpt * Db : 0, byte_lo = d.bytes_first ? 0 : Dt;
+    const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    const size_t need = composed_floats(d) * sizeof(float);
+    if (!d.workspace || d.workspace_bytes < need)
+        return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
+    float *u = (float *)d.workspace;
+    int rc;
+    for (int64_t r0 = 0; r0 < N; r0 += kSlabRows) {
+        const int64_t n = N - r0 < kSlabRows ? N - r0 : kSlabRows;
+        if ((rc = launch_gather_rows_placed(d.tokens + r0, nullptr, 4, n, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, nullptr, u + tok_lo, 1, K,
+                                            d.status, kStatusTokenOor, MOT_F32, stream))) return rc;
+        if ((rc = launch_gather_rows_placed(d.ids_a + r0 * bpt, d.ids_b ? d.ids_b + r0 * bpt : nullptr, 8, n * bpt, d.byte_table, d.byte_rows, Db,
+                                            d.norm_byte, eps, nullptr, u + byte_lo, bpt, K, d.status, kStatusByteOor, MOT_F32, stream))) return rc;
+        float *out = (float *)d.out + r0 * Dm;
+        if ((rc = launch_gemm_rows(u, K, n, (const float *)d.weight, K, K, Dm, out, Dm, true, stream, (const float *)d.bias))) return rc;
+        if (d.norm_out) {
+            hipLaunchKernelGGL(rows_rms_inplace_kernel, dim3((unsigned)((n + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, out, n, Dm, eps,
+                               d.out_row_rnorm ? d.out_row_rnorm + r0 : nullptr);
+            if ((rc = check_launch("rows_rms_inplace_kernel"))) return rc;
+        }
+    }
+    return MOT_OK;
+}
+
 size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d) {
+    if (composed_path(d)) return composed_floats(d) * sizeof(float);
     const int nt = nt_of(d.model_dim);
     if (nt < 0) return 0;
     const int K = d.tok_dim + d.bpt * d.byte_dim;
@@ -384,6 +442,7 @@ int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) { retu
 // `wt_prebuilt` (optional): the k-major, zero-padded weight operand [Kpad rows][wt_cols columns] supplied by
 // the caller (the backward passes W itself: for du = dy.W the nn.Linear layout already is k-major).
 int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuilt, int wt_cols, hipStream_t stream) {
+    if (!wt_prebuilt && composed_path(d)) return launch_composed(d, stream);
     const int nt = nt_of(d.model_dim);
     if (nt < 0) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: model_dim %d > 1024 is not built", d.model_dim);
     if ((d.tok_dim & 3) || (d.byte_dim & 3))
