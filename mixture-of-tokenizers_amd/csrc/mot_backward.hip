@@ -1194,15 +1194,18 @@ int launch_gemm_tn(const float *A_, int lda, int M, const float *B_, int ldb, in
 // C[n][c] = sum_r A[n][r] * (BT ? B[c][r] : B[r][c])   (A: n x R rows, C: n x Nc; leading dimensions lda / ldb / ldc), fp32 MFMA.
 // Same block shape and inner loop as gemm_tn_kernel -- 128 x 128 output block, 16 reduction indices per step, both operands in
 // LDS as [reduction index][block row / column], one conflict-free ds_read_b32 per MFMA operand -- with the operand whose rows
-// are contiguous along r (A always, B when BT) transposed on its way into LDS: a lane takes 4 consecutive r of ONE row and
-// the 64 lanes of a wave take 64 consecutive rows, so the four ds_write_b32 hit consecutive banks.  The reduction is whole
+// are contiguous along r (A always, B when BT) transposed on its way into LDS: a lane takes 4 consecutive r of one row, 4
+// lanes one 64-byte row segment, and writes them as four ds_write_b32 down a padded column.  The reduction is whole
 // inside the workgroup (plain stores).  The fused gather + norm kernel (mot_linear.hip) runs its dense-row mode at 48 % of
 // the fp32 MFMA peak; this loop reaches ~75 %.
 template <bool BT>
 __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb,
                                                              int R, int Nc, float *__restrict__ C, int ldc, const float *__restrict__ bias,
                                                              int accumulate) {
-    __shared__ __attribute__((aligned(16))) float lA[2][16 * 128], lB[2][16 * 128];
+    // transposed operands sit in LDS with a row stride of 132 floats: the 4 lanes that share a source row (coalesced 64-byte
+    // reads) then write to banks 16 apart, two lanes per bank -- the minimum for 64 dword writes
+    constexpr int LDA = 132, LDB = BT ? 132 : 128;
+    __shared__ __attribute__((aligned(16))) float lA[2][16 * LDA], lB[2][16 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
     const int64_t j0 = (int64_t)blockIdx.x * 128;
     const int k0 = blockIdx.y * 128;
@@ -1216,11 +1219,11 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__rest
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     const bool va = (lda & 3) == 0 && ((uintptr_t)A_ & 15) == 0, vb = (ldb & 3) == 0 && ((uintptr_t)B_ & 15) == 0;
     float4v ra[2], rb[2];
-    // rows-contiguous-along-r operand: thread -> (row = q & 127, 4 consecutive r starting at (q >> 7) * 4)
+    // rows-contiguous-along-r operand: thread -> (row = q >> 2, 4 consecutive r starting at (q & 3) * 4): 4 lanes read one 64-byte row segment
     auto load_t = [&](const float *P, int ld, int64_t row0, int64_t rows, bool vec, int r, float4v (&dst)[2]) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int q = p * kThreads + tid, row = q & 127, c4 = (q >> 7) * 4;
+            const int q = p * kThreads + tid, row = q >> 2, c4 = (q & 3) * 4;
             dst[p] = (float4v)(0.f);
             if (row0 + row < rows) {
                 const float *src = P + (row0 + row) * ld + r + c4;
@@ -1235,9 +1238,9 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__rest
     auto store_t = [&](float *L, const float4v (&srcv)[2]) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            const int q = p * kThreads + tid, row = q & 127, c4 = (q >> 7) * 4;
+            const int q = p * kThreads + tid, row = q >> 2, c4 = (q & 3) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) L[(c4 + e) * 128 + row] = srcv[p][e];
+            for (int e = 0; e < 4; ++e) L[(c4 + e) * 132 + row] = srcv[p][e];
         }
     };
     auto load_stage = [&](int r) {
@@ -1276,8 +1279,8 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__rest
         if (more) load_stage(r + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
-            const float a0 = lA[buf][(kk + h) * 128 + wm + li], a1 = lA[buf][(kk + h) * 128 + wm + 32 + li];
-            const float b0 = lB[buf][(kk + h) * 128 + wn + li], b1 = lB[buf][(kk + h) * 128 + wn + 32 + li];
+            const float a0 = lA[buf][(kk + h) * LDA + wm + li], a1 = lA[buf][(kk + h) * LDA + wm + 32 + li];
+            const float b0 = lB[buf][(kk + h) * LDB + wn + li], b1 = lB[buf][(kk + h) * LDB + wn + 32 + li];
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
