@@ -1124,6 +1124,7 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const float *__restri
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     // staging role: 16 rows x 32 float4 per operand = 512 float4 -> 2 per thread
     float4v ra[2], rb[2];
+    const bool va = (lda & 3) == 0 && ((uintptr_t)A_ & 15) == 0, vb = (ldb & 3) == 0 && ((uintptr_t)B_ & 15) == 0;   // 16-byte loads allowed
     auto load_stage = [&](int64_t r) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -1132,11 +1133,16 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_kernel(const float *__restri
             ra[p] = (float4v)(0.f); rb[p] = (float4v)(0.f);
             if (rr < r1) {
                 const float *pa = A_ + rr * lda + j0 + c4, *pb = B_ + rr * ldb + k0 + c4;
+                if (va && j0 + c4 + 3 < M) ra[p] = *(const float4v *)pa;
+                else
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {   // element-wise guards keep ragged right edges correct
-                    if (j0 + c4 + e < M) ra[p][e] = pa[e];
-                    if (k0 + c4 + e < Nc) rb[p][e] = pb[e];
-                }
+                    for (int e = 0; e < 4; ++e)   // element-wise guards keep ragged right edges correct
+                        if (j0 + c4 + e < M) ra[p][e] = pa[e];
+                if (vb && k0 + c4 + 3 < Nc) rb[p] = *(const float4v *)pb;
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (k0 + c4 + e < Nc) rb[p][e] = pb[e];
             }
         }
     };
@@ -1629,11 +1635,18 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     // 2. u = the seam tensors (norms and scalars applied), and dW += dy^T u
     const int64_t blk = 2048;
     (void)blk;
-    if ((rc = launch_gather_rows(d.tokens, nullptr, 4, N, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, d.scale_tok, utok, d.status, MOT_F32, stream))) return rc;
-    if ((rc = launch_gather_rows(d.ids_a, d.ids_b, 8, N * d.bpt, d.byte_table, d.byte_rows, d.byte_dim, d.norm_byte, eps, d.scale_byte, ubyte, d.status,
-                                 MOT_F32, stream))) return rc;
     const int tok_lo = d.bytes_first ? nbk : 0, byte_lo = d.bytes_first ? 0 : Dt;
     float *dW = (float *)gr.d_weight;
+    if (w16) {   // two dense seam tensors (the bf16 contraction takes token-minor copies of each)
+        if ((rc = launch_gather_rows(d.tokens, nullptr, 4, N, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, d.scale_tok, utok, d.status, MOT_F32, stream))) return rc;
+        if ((rc = launch_gather_rows(d.ids_a, d.ids_b, 8, N * d.bpt, d.byte_table, d.byte_rows, d.byte_dim, d.norm_byte, eps, d.scale_byte, ubyte, d.status,
+                                     MOT_F32, stream))) return rc;
+    } else {     // fp32: the concat operand u [N, K] itself, in the two (adjacent) scratch regions, so dW is ONE contraction
+        if ((rc = launch_gather_rows_placed(d.tokens, nullptr, 4, N, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, d.scale_tok, utok + tok_lo, 1, K,
+                                            d.status, kStatusTokenOor, MOT_F32, stream))) return rc;
+        if ((rc = launch_gather_rows_placed(d.ids_a, d.ids_b, 8, N * d.bpt, d.byte_table, d.byte_rows, d.byte_dim, d.norm_byte, eps, d.scale_byte,
+                                            utok + byte_lo, d.bpt, K, d.status, kStatusByteOor, MOT_F32, stream))) return rc;
+    }
     if (w16) {
         // 2'. dW on the bf16 MFMA: token-minor bf16 copies of dy and of the two parts of u, contraction over the tokens
         const Du16Layout U = du16_layout(d);
@@ -1649,8 +1662,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         if ((rc = launch_gemm_nt_bf16(dyT, Dm, uT, Dt, N, dW + tok_lo, K, stream))) return rc;
         if ((rc = launch_gemm_nt_bf16(dyT, Dm, uT + (size_t)Dt * N, nbk, N, dW + byte_lo, K, stream))) return rc;
     } else {
-        if ((rc = launch_gemm_tn(dyp, Dm, Dm, utok, Dt, Dt, N, dW + tok_lo, K, stream))) return rc;
-        if ((rc = launch_gemm_tn(dyp, Dm, Dm, ubyte, nbk, nbk, N, dW + byte_lo, K, stream))) return rc;
+        if ((rc = launch_gemm_tn(dyp, Dm, Dm, utok, K, K, N, dW, K, stream))) return rc;
     }
     hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(kThreads), 0, stream, iota, N);
     if (w16) {
