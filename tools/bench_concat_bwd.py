@@ -11,6 +11,7 @@ import golden_inputs as gi  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--ids", default="fused", choices=["fused", "given"], help="byte ids pulled in-kernel from the token->byte table, or precomputed (the module seam)")
 a = ap.parse_args()
 import mixture_of_tokenizers_amd as mot
 dev = torch.device("cuda", 0)
@@ -24,8 +25,13 @@ W = torch.nn.Parameter(((torch.rand((Dm, K), generator=g, device=dev) * 2 - 1) *
 toks = torch.from_numpy(gi.fineweb_like_tokens(12345, B, T, vocab=Vt)).to(dev)
 tab = torch.from_numpy(gi.widen_left_pad(gi.load_real_ttb8(), bpt)).to(dev)
 go = torch.randn((B, T, Dm), generator=g, device=dev).to(dt)
+if a.ids == "given":
+    from mixture_of_tokenizers_amd import data_creation as dc
+    src = dict(ids_a=dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457))
+else:
+    src = dict(ttb=tab, pull="left")
 def step():
-    x = mot.embed_mix(toks, Et, Eb, mode="concat_linear", bpt=bpt, ttb=tab, pull="left", weight=W, norm_tok=True, norm_byte=True, norm_out=True)
+    x = mot.embed_mix(toks, Et, Eb, mode="concat_linear", bpt=bpt, weight=W, norm_tok=True, norm_byte=True, norm_out=True, **src)
     x.backward(go)
 for _ in range(3): step()
 torch.cuda.synchronize()
@@ -33,4 +39,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(a.steps): step()
 e1.record(); torch.cuda.synchronize()
-print(json.dumps({"workload": f"concat fwd+bwd {B}x{T} Dt{Dt} Db{Db} Dm{Dm} {a.dtype}", "ms_fwd_bwd": e0.elapsed_time(e1) / a.steps}))
+print(json.dumps({"workload": f"concat fwd+bwd {B}x{T} Dt{Dt} Db{Db} Dm{Dm} {a.dtype} ids {a.ids}", "ms_fwd_bwd": e0.elapsed_time(e1) / a.steps}))
