@@ -12,15 +12,16 @@
 //   * token table: FineWeb-shaped ids are heavily skewed (the most frequent id takes ~3 % of all
 //     positions), and thousands of float atomics on one row serialise (measured: 4.5 ms per 524 k
 //     tokens, 28 % of the atomic ceiling).  So the positions are first counting-sorted by token id
-//     (histogram -> scan -> scatter, three tiny kernels); each wave then walks a window of kWindow
-//     SORTED positions, keeps the running gradient row of the current token in registers and issues
-//     one atomic row-add per run of equal tokens.  Lane l owns elements l, l+64, ... of the row, so
-//     every atomic wave-instruction covers 256 contiguous bytes (the shape that runs at the chip-wide
-//     atomic rate); float4-per-lane would spread each instruction over 1 KiB.
-//   * byte table (458 rows hit 8.4 M times per step): privatised in LDS per workgroup
-//     (ds_add_f32), flushed once with contiguous global atomics.
-// 512-thread workgroups, one per CU (the LDS copy of the byte-table gradient is ~88 KB), persistent
-// over tokens.  Byte ids are taken as given (the forward returns them), so no tile machinery here.
+//     (bwd_rank_kernel -> bwd_scan_kernel -> bwd_place_kernel, three small kernels); each wave then
+//     walks a contiguous stretch of the SORTED positions, keeps the running gradient row of the current
+//     token in registers and issues one atomic row-add per run of equal tokens.  Lane l owns elements
+//     l, l+64, ... of the row, so every atomic wave-instruction covers 256 contiguous bytes (the shape
+//     that runs at the chip-wide atomic rate); float4-per-lane would spread each instruction over 1 KiB.
+//   * byte table (458 rows hit 8.4 M times per step): privatised in LDS per workgroup as 64-bit fixed
+//     point (ds_add_u64; ds_add_f32 issues one lane at a time on gfx950), flushed once with contiguous
+//     global float atomics.
+// 512-thread workgroups, one per CU (the LDS copy of the byte-table gradient takes up to 150 KB).
+// Byte ids are taken as given (the forward returns them), so no tile machinery here.
 // Float atomics make the sums order-dependent in the last bits, like the reference's own GPU
 // embedding backward; the parity tests state the tolerance they use against a float64 evaluation.
 #include <stdlib.h>
@@ -329,11 +330,12 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
 
 // ------------------------------------------------------------------------------------------
 // Lean variant for the layouts where a row is "full": SUM / NOOP with D == 64 * NE (the headline shapes: 768, 1024,
-// 2048, 256 ...).  Same algorithm as embed_mix_bwd_kernel, minus everything the general layout needs per element
-// (range guards, the split token/byte row layout of CONCAT_LINEAR, the two-id-tensor norm): the slot and
-// within-slot index of a lane's elements are computed once, a token's byte ids are loaded once by lanes < bpt and
-// handed out with ds_bpermute, and the per-slot sums of the byte-norm backward use the same fixed-point LDS
-// accumulation as the table.  ~4x fewer instructions per token than the general kernel.
+// 2048, 256 ...) and the CONCAT_LINEAR scatter whose row splits into a token part and a byte part on 64-element
+// boundaries.  Same algorithm as embed_mix_bwd_kernel, minus everything the general layout needs per element: the slot
+// and within-slot index of a lane's elements are computed once, position and token id are wave-uniform scalars (rows
+// are addressed as SGPR base + immediates), a token's byte ids are loaded once by lanes < bpt and handed out with
+// ds_bpermute, the token row is read once per run of equal tokens, and the byte-table adds are straight-line 64-bit
+// fixed-point LDS atomics.  ~5x fewer instructions per position than the general kernel.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long to_fixed(float v, int k) {
     // round(v * 2^k) as two's complement in 64 bits, |v * 2^k| < 2^51: add 1.5 * 2^52 and read the mantissa
@@ -426,12 +428,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     int cur = -1;
     auto flush = [&]() {
         if (cur < 0 || (A.abl & 2)) return;
-        char *drow = (char *)(A.d_tok + ((int64_t)((A.abl & 32) ? 0 : cur) * A.Dt - A.tok_lo));   // abl 32: one hot row
-        if (A.abl & 16) {   // abl 16: plain stores
-#pragma unroll
-            for (int j = 0; j < NE; ++j) *(float *)(drow + (lane4 + 256u * j)) = acc[j];
-            return;
-        }
+        char *drow = (char *)(A.d_tok + ((int64_t)cur * A.Dt - A.tok_lo));
 #pragma unroll
         for (int j = 0; j < NE; ++j)
             if (tmask >> j & 1) atomicAdd((float *)(drow + (BF ? 2u * lane4 + 512u * (j >> 1) + 4u * (j & 1) : lane4 + 256u * j)), acc[j]);
