@@ -488,10 +488,8 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
 
 size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d) { return attn_bwd_layout(d).total * 4; }
 
-// out[n][Nout] = rows[n][Kc] . W[Kc][Nout]  (W k-major, unpadded): the plain dense MFMA kernel
-static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *W, int Nout, float *out, float *wk, const int32_t *iota, const float *byte0,
-                             uint32_t *status, hipStream_t stream) {
-    (void)wk; (void)iota; (void)byte0; (void)status;
+// out[n][Nout] = rows[n][Kc] . W[Kc][Nout]  (W with the reduction index as its row index): the plain dense MFMA kernel
+static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *W, int Nout, float *out, hipStream_t stream) {
     return launch_gemm_rows(rows, Kc, n, W, Nout, Kc, Nout, out, Nout, false, stream);
 }
 
@@ -504,7 +502,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     float *ws = (float *)d.workspace;
     float *q = ws + L.q, *y = ws + L.y, *kpre = ws + L.kpre, *vpre = ws + L.vpre, *kn = ws + L.kn, *vl = ws + L.vl, *dy = ws + L.dy, *dq = ws + L.dq;
     float *dkn_pos = ws + L.dkn_pos, *dvl_pos = ws + L.dvl_pos, *dkn_tab = ws + L.dkn_tab, *dvl_tab = ws + L.dvl_tab, *dkv = ws + L.dkv;
-    float *xkv = ws + L.xkv, *dxkv = ws + L.dxkv, *xq = ws + L.xq, *dxq = ws + L.dxq, *byte0 = ws + L.byte0, *wk = ws + L.wk, *lin = ws + L.lin;
+    float *xkv = ws + L.xkv, *dxkv = ws + L.dxkv, *xq = ws + L.xq, *dxq = ws + L.dxq, *byte0 = ws + L.byte0, *lin = ws + L.lin;
     int32_t *ids32 = (int32_t *)(ws + L.ids32), *iota = (int32_t *)(ws + L.iota);
     void *emb_ws = ws + L.emb;
     const size_t lin_bytes = L.lin_floats * 4;
@@ -548,7 +546,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     }
     // ---- c_proj:  dW_p += g^T y;  dy = g W_p   (proj_w [D, HD] is the k-major operand of g[T, D] -> dy[T, HD])
     if (gr.d_proj_w && (rc = launch_gemm_tn(g_out, D, D, y, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
-    if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, wk, iota, byte0, d.status, stream))) return rc;
+    if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, stream))) return rc;
     // ---- attention
     AttnBwdArgs B;
     B.q_pre = q; B.dy = dy; B.kn = kn; B.vpre = vpre; B.lambda = d.lambda_factor; B.ids = d.ids_a; B.rows = R; B.T = T; B.bpt = d.bpt; B.H = H;
@@ -575,7 +573,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     if ((rc = check_launch("rows_norm_kernel"))) return rc;
     if (gr.d_kv_w && (rc = launch_gemm_tn(dkv, 2 * HD, 2 * HD, xkv, D, D, R, (float *)gr.d_kv_w, D, stream))) return rc;
     if (gr.d_byte_table) {
-        if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, wk, iota, byte0, d.status, stream))) return rc;   // kv_w as [2 HD, D]
+        if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;   // kv_w as [2 HD, D]
         hipLaunchKernelGGL(byte_rows_bwd_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, dxkv, R, D,
                            d.norm_byte, eps, (float *)gr.d_byte_table);
         if ((rc = check_launch("byte_rows_bwd_kernel"))) return rc;
@@ -587,7 +585,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         if ((rc = launch_gemm_tn(dq, HD, HD, xq, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
     }
     if (gr.d_tok_table) {
-        if ((rc = dense_gemm_kmajor(dq, T, HD, (const float *)d.q_w, D, dxq, wk, iota, byte0, d.status, stream))) return rc;   // q_w [HD, D]
+        if ((rc = dense_gemm_kmajor(dq, T, HD, (const float *)d.q_w, D, dxq, stream))) return rc;   // q_w [HD, D]
         noop_bwd_desc(ed, d.tokens, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, d.status);
         ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
         eg.grad_out = dxq; eg.d_tok_table = gr.d_tok_table;
