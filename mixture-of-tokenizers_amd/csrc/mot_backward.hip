@@ -1202,9 +1202,8 @@ int launch_gemm_tn(const float *A_, int lda, int M, const float *B_, int ldb, in
 // inside the workgroup (plain stores).  The fused gather + norm kernel (mot_linear.hip) runs its dense-row mode at 48 % of
 // the fp32 MFMA peak; this loop reaches ~75 %.
 template <bool BT>
-__global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb,
-                                                             int R, int Nc, float *__restrict__ C, int ldc, const float *__restrict__ bias,
-                                                             int accumulate) {
+__device__ __forceinline__ void gemm_rows_body(const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb,
+                                               int R, int Nc, float *__restrict__ C, int ldc, const float *__restrict__ bias, int accumulate) {
     // transposed operands sit in LDS with a row stride of 132 floats: the 4 lanes that share a source row (coalesced 64-byte
     // reads) then write to banks 16 apart, two lanes per bank -- the minimum for 64 dword writes
     constexpr int LDA = 132, LDB = BT ? 132 : 128;
@@ -1213,13 +1212,17 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__rest
     const int64_t j0 = (int64_t)blockIdx.x * 128;
     const int k0 = blockIdx.y * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    f32x16b acc[2][2];
+    // acc is the MFMA accumulator of kFold reduction steps at a time; it is then folded into `sum` with vector adds and
+    // restarted, so no fp32 summation chain is longer than 8 * kFold MFMA steps (blocked summation, like the reference's
+    // CPU sgemm: one chain over K = 768 ends up 4x as far from the float64 result as the reference, the parity bar is 2x)
+    constexpr int kFold = 8;
+    f32x16b acc[2][2], sum[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[a][b][r] = 0.f; sum[a][b][r] = 0.f; }
     const bool va = (lda & 3) == 0 && ((uintptr_t)A_ & 15) == 0, vb = (ldb & 3) == 0 && ((uintptr_t)B_ & 15) == 0;
     float4v ra[2], rb[2];
     // rows-contiguous-along-r operand: thread -> (row = q >> 2, 4 consecutive r starting at (q & 3) * 4): 4 lanes read one 64-byte row segment
@@ -1289,6 +1292,14 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__rest
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+        if (((r >> 4) & (kFold - 1)) == kFold - 1) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) { sum[a][b][q] += acc[a][b][q]; acc[a][b][q] = 0.f; }
+        }
         if (more) store_stage(buf ^ 1);
         __syncthreads();
     }
@@ -1301,7 +1312,7 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__rest
                 const int64_t j = j0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int k = k0 + wn + b * 32 + li;
                 if (j < n && k < Nc) {
-                    float v = acc[a][b][r];
+                    float v = sum[a][b][r] + acc[a][b][r];
                     if (bias) v += bias[k];
                     if (accumulate) v += C[j * ldc + k];
                     C[j * ldc + k] = v;
@@ -1309,10 +1320,21 @@ __global__ __launch_bounds__(kThreads) void gemm_rows_kernel(const float *__rest
             }
 }
 
-// The reduction is cut into launches of at most kGemmRowsPass indices, the later ones adding to C: one fp32 MFMA summation
-// chain over K = 1024 ends up 2.1x as far from the float64 result as the reference's blocked CPU sgemm (the parity bar is
-// 2x); a second accumulator set inside the kernel would halve its occupancy and cost 10 %.
-constexpr int kGemmRowsPass = 768;
+// The register budget is set per variant: with B transposed the body fits 168 registers (3 waves per SIMD); with B in its
+// natural layout that cap spills inside the loop (0.92 ms instead of 0.72), so that variant runs at 2 waves per SIMD.
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))) void gemm_rows_bt_kernel(
+    const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb, int R, int Nc, float *__restrict__ C, int ldc,
+    const float *__restrict__ bias, int accumulate) {
+    gemm_rows_body<true>(A_, lda, n, B_, ldb, R, Nc, C, ldc, bias, accumulate);
+}
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 4))) void gemm_rows_kernel(
+    const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb, int R, int Nc, float *__restrict__ C, int ldc,
+    const float *__restrict__ bias, int accumulate) {
+    gemm_rows_body<false>(A_, lda, n, B_, ldb, R, Nc, C, ldc, bias, accumulate);
+}
+
+// (the reduction can be cut into launches that add to C; with the in-kernel blocked summation one launch covers any K)
+constexpr int kGemmRowsPass = 1 << 30;
 int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed,
                      hipStream_t stream, const float *bias) {
     if (n <= 0 || Nc <= 0) return MOT_OK;
@@ -1323,10 +1345,10 @@ int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int l
         const int rn = R - r0 < kGemmRowsPass ? R - r0 : kGemmRowsPass;
         const float *a = A_ + r0, *b = b_transposed ? B_ + r0 : B_ + (int64_t)r0 * ldb;
         if (b_transposed)
-            hipLaunchKernelGGL(gemm_rows_kernel<true>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
+            hipLaunchKernelGGL(gemm_rows_bt_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
                                r0 ? nullptr : bias, r0 ? 1 : 0);
         else
-            hipLaunchKernelGGL(gemm_rows_kernel<false>, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
+            hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
                                r0 ? nullptr : bias, r0 ? 1 : 0);
         if (r0 + kGemmRowsPass >= R) break;
     }
