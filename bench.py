@@ -315,8 +315,9 @@ def main():
             res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                                "frac": tf / peak, "traffic": traffic,
                                "kernel": ("embed_mix_linear_bf16_kernel" if args.dtype != "f32" else
-                                          "embed_mix_linear_kernel" if args.ids == "fused" else
-                                          "gather_rows_kernel x2 + gemm_rows_kernel + rows_rms_inplace_kernel (whole call)"),
+                                          "embed_mix_linear_kernel" if os.environ.get("MOT_LIN_FUSED") else
+                                          ("tokens_to_bytes + pull_bytes + " if args.ids == "fused" else "") +
+                                          "gather_rows x2 + gemm_rows_bt_kernel + rows_rms_inplace (whole call)"),
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
         if args.backward and mode == "sum":
             from mixture_of_tokenizers_amd import data_creation as dc

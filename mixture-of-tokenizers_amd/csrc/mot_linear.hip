@@ -359,12 +359,17 @@ static int nt_of(int Dm) {
 // scratch stays bounded.  The fused kernel remains the path for ids pulled in-kernel from the token->byte table.
 constexpr int64_t kSlabRows = 65536;
 static bool composed_path(const MotEmbedMixDesc &d) {
-    static const bool off = getenv("MOT_LIN_FUSED") != nullptr;   // dev / A-B switch: always the fused tile kernel
-    return !off && d.id_source == MOT_IDS_GIVEN && d.bpt > 0 && !d.scale_tok && !d.scale_byte;
+    if (getenv("MOT_LIN_FUSED")) return false;   // A-B / test switch: the fused tile kernel for everything (read per call)
+    return d.bpt > 0 && !d.scale_tok && !d.scale_byte;
 }
 static size_t composed_floats(const MotEmbedMixDesc &d) {
     const int64_t n = d.n_rows * d.tokens_per_row;
     return (size_t)(n < kSlabRows ? n : kSlabRows) * (size_t)(d.tok_dim + d.bpt * d.byte_dim);
+}
+// ids pulled from the token->byte table: the two index kernels of the loader path run first, into the caller's out_ids_*
+// buffers when it asked for them, else into scratch behind u (2 x tokens x bpt int64)
+static size_t composed_id_words(const MotEmbedMixDesc &d) {
+    return d.id_source == MOT_IDS_FROM_TTB ? 2 * (size_t)(d.n_rows * d.tokens_per_row) * (size_t)d.bpt : 0;
 }
 
 // x[r] *= rsqrt(mean(x[r]^2) + eps) in place, one wave per row; the factor is kept for the backward
@@ -380,6 +385,60 @@ __global__ __launch_bounds__(kThreads) void rows_rms_inplace_kernel(float *__res
     if (row_rnorm && lane == 0) row_rnorm[r] = rs;
 }
 
+// the statistics of runs/79_*.py:484-488 from the two id tensors: tokens, byte slots, pads before the pull, pads after
+__global__ __launch_bounds__(kThreads) void count_pads_kernel(const int64_t *__restrict__ padded, const int64_t *__restrict__ after, int64_t n_slots,
+                                                              int64_t pad, int64_t n_tokens, int64_t *counters) {
+    int before = 0, aft = 0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_slots; i += (int64_t)gridDim.x * kThreads) {
+        before += padded[i] == pad;
+        aft += after[i] == pad;
+    }
+    before = (int)wave_sum((float)before);   // <= 64 * a few thousand per wave: exact in fp32
+    aft = (int)wave_sum((float)aft);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd((unsigned long long *)counters + 2, (unsigned long long)before);
+        atomicAdd((unsigned long long *)counters + 3, (unsigned long long)aft);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd((unsigned long long *)counters + 0, (unsigned long long)n_tokens);
+        atomicAdd((unsigned long long *)counters + 1, (unsigned long long)n_slots);
+    }
+}
+
+static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream);
+
+static int launch_composed_from_ttb(const MotEmbedMixDesc &d, hipStream_t stream) {
+    const int64_t N = d.n_rows * d.tokens_per_row, slots = N * d.bpt;
+    const size_t need = composed_floats(d) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
+    if (!d.workspace || d.workspace_bytes < need)
+        return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
+    int64_t *ws_ids = (int64_t *)((float *)d.workspace + ((composed_floats(d) + 1) & ~(size_t)1));
+    int64_t *padded = d.out_ids_padded ? d.out_ids_padded : ws_ids;
+    int64_t *pulled = d.out_ids_pulled ? d.out_ids_pulled : ws_ids + slots;
+    int rc;
+    if ((rc = launch_tokens_to_bytes(d.tokens, N, d.ttb, d.ttb_elem_bytes, d.ttb_rows, d.bpt, padded, d.status, stream))) return rc;
+    const int64_t *after = padded;
+    if (d.pull_dir != MOT_PULL_NONE) {
+        if ((rc = launch_pull_bytes(padded, pulled, d.n_rows, d.tokens_per_row, d.bpt, d.pad_byte, d.eot_byte,
+                                    d.pull_dir == MOT_PULL_LEFT ? kPullLeft : kPullRight, stream))) return rc;
+        after = pulled;
+    } else if (d.out_ids_pulled) {   // nothing is pulled: that output is the padded tensor again
+        if ((rc = launch_tokens_to_bytes(d.tokens, N, d.ttb, d.ttb_elem_bytes, d.ttb_rows, d.bpt, d.out_ids_pulled, nullptr, stream))) return rc;
+    }
+    if (d.counters) {
+        int64_t blocks = (slots + kThreads * 16 - 1) / (kThreads * 16);
+        if (blocks > 1024) blocks = 1024;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(count_pads_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, padded, after, slots, (int64_t)d.pad_byte, N, d.counters);
+        if ((rc = check_launch("count_pads_kernel"))) return rc;
+    }
+    MotEmbedMixDesc g = d;
+    g.id_source = MOT_IDS_GIVEN;
+    g.ids_a = after;
+    g.ids_b = d.add_padded ? padded : nullptr;
+    return launch_composed(g, stream);
+}
+
 static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
     const int64_t N = d.n_rows * d.tokens_per_row;
     const int Dt = d.tok_dim, Db = d.byte_dim, bpt = d.bpt, K = Dt + bpt * Db, Dm = d.model_dim;
@@ -389,6 +448,7 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
     if (!d.workspace || d.workspace_bytes < need)
         return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
     float *u = (float *)d.workspace;
+    if (N == 0) return MOT_OK;
     int rc;
     for (int64_t r0 = 0; r0 < N; r0 += kSlabRows) {
         const int64_t n = N - r0 < kSlabRows ? N - r0 : kSlabRows;
@@ -408,7 +468,7 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
 }
 
 size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d) {
-    if (composed_path(d)) return composed_floats(d) * sizeof(float);
+    if (composed_path(d)) return ((composed_floats(d) + 1) & ~(size_t)1) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
     const int nt = nt_of(d.model_dim);
     if (nt < 0) return 0;
     const int K = d.tok_dim + d.bpt * d.byte_dim;
@@ -442,7 +502,7 @@ int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) { retu
 // `wt_prebuilt` (optional): the k-major, zero-padded weight operand [Kpad rows][wt_cols columns] supplied by
 // the caller (the backward passes W itself: for du = dy.W the nn.Linear layout already is k-major).
 int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuilt, int wt_cols, hipStream_t stream) {
-    if (!wt_prebuilt && composed_path(d)) return launch_composed(d, stream);
+    if (!wt_prebuilt && composed_path(d)) return d.id_source == MOT_IDS_FROM_TTB ? launch_composed_from_ttb(d, stream) : launch_composed(d, stream);
     const int nt = nt_of(d.model_dim);
     if (nt < 0) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: model_dim %d > 1024 is not built", d.model_dim);
     if ((d.tok_dim & 3) || (d.byte_dim & 3))
