@@ -316,10 +316,12 @@ class ByteMixin(nn.Module):  # train_gpt.py:467-480
 
 
 class FusedFrontEnd(nn.Module):
-    """Loader + embed + mixin in one launch: tokens (B,T) -> x (B,T,model_dim), with the
-    token->byte gather and the pull done inside the kernel (byte ids never reach HBM).  Holds the
-    same submodules under the reference's names (``embed``, ``byte_mixin``), so a GPT can adopt its
-    parameters directly; the token->byte table is a non-persistent integer buffer."""
+    """Loader + embed + mixin in one library call: tokens (B,T) -> x (B,T,model_dim), with the
+    token->byte gather and the pull done on the device inside that call (index kernels into scratch,
+    then gather, contraction and output norm; ``MOT_LIN_FUSED=1`` selects the one-launch tile kernel in
+    which the byte ids never leave LDS).  Holds the same submodules under the reference's names
+    (``embed``, ``byte_mixin``), so a GPT can adopt its parameters directly; the token->byte table is
+    a non-persistent integer buffer."""
 
     def __init__(self, dims: ModelDims, vocab_size: int, byte_params: ByteHyperparameters, ttb, max_seq_len: int = 1024,
                  pad_byte: int = 456, eot_byte: int = 457):
