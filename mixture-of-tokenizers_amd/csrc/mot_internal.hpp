@@ -43,6 +43,13 @@ int launch_gemm_tn(const float *A, int lda, int M, const float *B, int ldb, int 
 // C[n][c] = sum_r A[n][r] * (b_transposed ? B[c][r] : B[r][c]) (+ bias[c]), fp32 MFMA, plain stores
 int launch_gemm_rows(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed, hipStream_t stream,
                      const float *bias = nullptr);
+// the composed concat + linear forward (index kernels, seam gather, dense MFMA kernel, row norm), fp32 and bf16 (mot_linear.hip)
+bool embed_mix_linear_is_composed(const MotEmbedMixDesc &d);
+size_t embed_mix_linear_composed_workspace_bytes(const MotEmbedMixDesc &d);
+int launch_embed_mix_linear_composed(const MotEmbedMixDesc &d, hipStream_t stream);
+// C[n][c] = sum_r A[n][r] * B[c][r] (+ bias[c]) for bf16 A, B (and bias), fp32 accumulation, C bf16 or fp32
+int launch_gemm_rows_bf16(const void *A, int lda, int64_t n, const void *B, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
+                          const void *bias, hipStream_t stream);
 int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream);
 // zero n 32-bit words with a kernel (not hipMemsetAsync: a memset node aborts on graph replay with this runtime)
 int launch_zero_words(void *p, int64_t n_words, hipStream_t stream);

@@ -358,13 +358,16 @@ static int nt_of(int Dm) {
 // over tokens x K floats, which the faster contraction more than pays for; it is built in slabs of kSlabRows rows so the
 // scratch stays bounded.  The fused kernel remains the path for ids pulled in-kernel from the token->byte table.
 constexpr int64_t kSlabRows = 65536;
-static bool composed_path(const MotEmbedMixDesc &d) {
-    if (getenv("MOT_LIN_FUSED")) return false;   // A-B / test switch: the fused tile kernel for everything (read per call)
+bool embed_mix_linear_is_composed(const MotEmbedMixDesc &d) {
+    if (getenv("MOT_LIN_FUSED")) return false;   // A-B / test switch: the fused tile kernels for everything (read per call)
     return d.bpt > 0 && !d.scale_tok && !d.scale_byte;
 }
+static bool composed_path(const MotEmbedMixDesc &d) { return embed_mix_linear_is_composed(d); }
+// u in units of 4 bytes (fp32: one element; bf16: two), rounded up to a multiple of 4 so that what follows stays 16-byte aligned
 static size_t composed_floats(const MotEmbedMixDesc &d) {
     const int64_t n = d.n_rows * d.tokens_per_row;
-    return (size_t)(n < kSlabRows ? n : kSlabRows) * (size_t)(d.tok_dim + d.bpt * d.byte_dim);
+    const size_t elems = (size_t)(n < kSlabRows ? n : kSlabRows) * (size_t)(d.tok_dim + d.bpt * d.byte_dim);
+    return ((d.dtype == MOT_BF16 ? (elems + 1) / 2 : elems) + 3) & ~(size_t)3;
 }
 // ids pulled from the token->byte table: the two index kernels of the loader path run first, into the caller's out_ids_*
 // buffers when it asked for them, else into scratch behind u (2 x tokens x bpt int64)
@@ -372,16 +375,47 @@ static size_t composed_id_words(const MotEmbedMixDesc &d) {
     return d.id_source == MOT_IDS_FROM_TTB ? 2 * (size_t)(d.n_rows * d.tokens_per_row) * (size_t)d.bpt : 0;
 }
 
-// x[r] *= rsqrt(mean(x[r]^2) + eps) in place, one wave per row; the factor is kept for the backward
-__global__ __launch_bounds__(kThreads) void rows_rms_inplace_kernel(float *__restrict__ x, int64_t n, int dim, float eps, float *__restrict__ row_rnorm) {
+// x[r] *= rsqrt(mean(x[r]^2) + eps) in place, one wave per row; the factor is kept for the backward.  For bf16 the row IS
+// the bf16 tensor the reference's CastedLinear returns (train_gpt.py:185-186); norm() upcasts it (172-173), one rounding on store.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void rows_rms_inplace_kernel(T *__restrict__ x, int64_t n, int dim, float eps, float *__restrict__ row_rnorm) {
+    using vec_t = typename Elem<T>::vec;            // 16 bytes: 4 floats / 8 bf16, widened to floats
+    constexpr int VEC = Elem<T>::kVec, kKeep = 4;    // a lane keeps up to kKeep vectors of the row between the two passes
+    auto sumsq = [](const vec_t &v) {
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) t += v[e] * v[e];
+        return t;
+    };
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     if (r >= n) return;
-    float *p = x + r * dim;
+    T *p = x + r * dim;
+    if ((dim % VEC) == 0 && (((uintptr_t)x | ((size_t)dim * sizeof(T))) & 15) == 0) {
+        const int nv = dim / VEC;
+        vec_t keep[kKeep];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < kKeep; ++i) {
+            const int j = lane + 64 * i;
+            keep[i] = j < nv ? Elem<T>::loadv(p + VEC * j) : (vec_t)(0.f);
+            ss += sumsq(keep[i]);
+        }
+        for (int j = lane + 64 * kKeep; j < nv; j += 64) ss += sumsq(Elem<T>::loadv(p + VEC * j));
+        const float rs = rms_scale(wave_sum(ss), dim, eps);
+#pragma unroll
+        for (int i = 0; i < kKeep; ++i) {
+            const int j = lane + 64 * i;
+            if (j < nv) Elem<T>::storev_nt(p + VEC * j, keep[i] * rs);
+        }
+        for (int j = lane + 64 * kKeep; j < nv; j += 64) Elem<T>::storev_nt(p + VEC * j, Elem<T>::loadv(p + VEC * j) * rs);
+        if (row_rnorm && lane == 0) row_rnorm[r] = rs;
+        return;
+    }
     float ss = 0.f;
-    for (int j = lane; j < dim; j += 64) ss += p[j] * p[j];
+    for (int j = lane; j < dim; j += 64) { const float v = (float)p[j]; ss += v * v; }
     const float rs = rms_scale(wave_sum(ss), dim, eps);
-    for (int j = lane; j < dim; j += 64) p[j] *= rs;
+    for (int j = lane; j < dim; j += 64) p[j] = (T)((float)p[j] * rs);
     if (row_rnorm && lane == 0) row_rnorm[r] = rs;
 }
 
@@ -412,7 +446,7 @@ static int launch_composed_from_ttb(const MotEmbedMixDesc &d, hipStream_t stream
     const size_t need = composed_floats(d) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
     if (!d.workspace || d.workspace_bytes < need)
         return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
-    int64_t *ws_ids = (int64_t *)((float *)d.workspace + ((composed_floats(d) + 1) & ~(size_t)1));
+    int64_t *ws_ids = (int64_t *)((float *)d.workspace + composed_floats(d));
     int64_t *padded = d.out_ids_padded ? d.out_ids_padded : ws_ids;
     int64_t *pulled = d.out_ids_pulled ? d.out_ids_pulled : ws_ids + slots;
     int rc;
@@ -443,32 +477,45 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
     const int64_t N = d.n_rows * d.tokens_per_row;
     const int Dt = d.tok_dim, Db = d.byte_dim, bpt = d.bpt, K = Dt + bpt * Db, Dm = d.model_dim;
     const int tok_lo = d.bytes_first ? bpt * Db : 0, byte_lo = d.bytes_first ? 0 : Dt;
-    const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    const bool bf = d.dtype == MOT_BF16;
+    const size_t esz = bf ? 2 : 4;
+    const float eps = d.eps > 0.f ? d.eps : (bf ? kBf16Eps : FLT_EPSILON);
     const size_t need = composed_floats(d) * sizeof(float);
     if (!d.workspace || d.workspace_bytes < need)
         return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
-    float *u = (float *)d.workspace;
+    char *u = (char *)d.workspace;
     if (N == 0) return MOT_OK;
     int rc;
     for (int64_t r0 = 0; r0 < N; r0 += kSlabRows) {
         const int64_t n = N - r0 < kSlabRows ? N - r0 : kSlabRows;
-        if ((rc = launch_gather_rows_placed(d.tokens + r0, nullptr, 4, n, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, nullptr, u + tok_lo, 1, K,
-                                            d.status, kStatusTokenOor, MOT_F32, stream))) return rc;
+        if ((rc = launch_gather_rows_placed(d.tokens + r0, nullptr, 4, n, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, nullptr, u + tok_lo * esz, 1, K,
+                                            d.status, kStatusTokenOor, d.dtype, stream))) return rc;
         if ((rc = launch_gather_rows_placed(d.ids_a + r0 * bpt, d.ids_b ? d.ids_b + r0 * bpt : nullptr, 8, n * bpt, d.byte_table, d.byte_rows, Db,
-                                            d.norm_byte, eps, nullptr, u + byte_lo, bpt, K, d.status, kStatusByteOor, MOT_F32, stream))) return rc;
-        float *out = (float *)d.out + r0 * Dm;
-        if ((rc = launch_gemm_rows(u, K, n, (const float *)d.weight, K, K, Dm, out, Dm, true, stream, (const float *)d.bias))) return rc;
-        if (d.norm_out) {
-            hipLaunchKernelGGL(rows_rms_inplace_kernel, dim3((unsigned)((n + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, out, n, Dm, eps,
-                               d.out_row_rnorm ? d.out_row_rnorm + r0 : nullptr);
-            if ((rc = check_launch("rows_rms_inplace_kernel"))) return rc;
+                                            d.norm_byte, eps, nullptr, u + byte_lo * esz, bpt, K, d.status, kStatusByteOor, d.dtype, stream))) return rc;
+        char *out = (char *)d.out + r0 * Dm * esz;
+        float *rr = d.out_row_rnorm ? d.out_row_rnorm + r0 : nullptr;
+        const unsigned nb = (unsigned)((n + kWaves - 1) / kWaves);
+        if (bf) {
+            if ((rc = launch_gemm_rows_bf16(u, K, n, d.weight, K, K, Dm, out, Dm, true, d.bias, stream))) return rc;
+            if (d.norm_out) hipLaunchKernelGGL(rows_rms_inplace_kernel<__bf16>, dim3(nb), dim3(kThreads), 0, stream, (__bf16 *)out, n, Dm, eps, rr);
+        } else {
+            if ((rc = launch_gemm_rows((const float *)u, K, n, (const float *)d.weight, K, K, Dm, (float *)out, Dm, true, stream, (const float *)d.bias))) return rc;
+            if (d.norm_out) hipLaunchKernelGGL(rows_rms_inplace_kernel<float>, dim3(nb), dim3(kThreads), 0, stream, (float *)out, n, Dm, eps, rr);
         }
+        if (d.norm_out && (rc = check_launch("rows_rms_inplace_kernel"))) return rc;
     }
     return MOT_OK;
 }
 
+size_t embed_mix_linear_composed_workspace_bytes(const MotEmbedMixDesc &d) {
+    return composed_floats(d) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
+}
+int launch_embed_mix_linear_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
+    return d.id_source == MOT_IDS_FROM_TTB ? launch_composed_from_ttb(d, stream) : launch_composed(d, stream);
+}
+
 size_t embed_mix_linear_workspace_bytes(const MotEmbedMixDesc &d) {
-    if (composed_path(d)) return ((composed_floats(d) + 1) & ~(size_t)1) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
+    if (composed_path(d)) return embed_mix_linear_composed_workspace_bytes(d);
     const int nt = nt_of(d.model_dim);
     if (nt < 0) return 0;
     const int K = d.tok_dim + d.bpt * d.byte_dim;
@@ -502,7 +549,7 @@ int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream) { retu
 // `wt_prebuilt` (optional): the k-major, zero-padded weight operand [Kpad rows][wt_cols columns] supplied by
 // the caller (the backward passes W itself: for du = dy.W the nn.Linear layout already is k-major).
 int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuilt, int wt_cols, hipStream_t stream) {
-    if (!wt_prebuilt && composed_path(d)) return d.id_source == MOT_IDS_FROM_TTB ? launch_composed_from_ttb(d, stream) : launch_composed(d, stream);
+    if (!wt_prebuilt && composed_path(d)) return launch_embed_mix_linear_composed(d, stream);
     const int nt = nt_of(d.model_dim);
     if (nt < 0) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: model_dim %d > 1024 is not built", d.model_dim);
     if ((d.tok_dim & 3) || (d.byte_dim & 3))

@@ -368,10 +368,12 @@ static size_t ws_packed_w_bytes(const MotEmbedMixDesc &d) {
     return (size_t)nsteps * DmPad * kBK16 * 2;
 }
 size_t embed_mix_linear_bf16_workspace_bytes(const MotEmbedMixDesc &d) {
+    if (embed_mix_linear_is_composed(d)) return embed_mix_linear_composed_workspace_bytes(d);
     return (ws_byte_floats(d) + ws_tok_floats(d)) * sizeof(float) + ws_packed_w_bytes(d);
 }
 
 int launch_embed_mix_linear_bf16(const MotEmbedMixDesc &d, hipStream_t stream) {
+    if (embed_mix_linear_is_composed(d)) return launch_embed_mix_linear_composed(d, stream);   // bpt > 0: not the dense-row mode of the backward
     if (d.model_dim > 1024) return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear bf16: model_dim %d > 1024 is not built", d.model_dim);
     if ((d.tok_dim & 7) || (d.byte_dim & 7))
         return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear bf16: tok_dim/byte_dim must be multiples of 8 (got %d, %d)", d.tok_dim, d.byte_dim);
