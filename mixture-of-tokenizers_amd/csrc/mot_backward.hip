@@ -1685,7 +1685,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     }
     hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(kThreads), 0, stream, iota, N);
     if (w16) {
-        // 3'. du on the bf16 MFMA: bf16(dy) rows x W^T, through the forward bf16 kernel in dense-row mode, widened for step 4
+        // 3'. du on the bf16 MFMA: bf16(dy) rows x W^T on the dense bf16 kernel
         const Du16Layout U = du16_layout(d);
         __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16), *wt16 = (__bf16 *)(ws16 + U.wt16), *du16 = (__bf16 *)(ws16 + U.du16);
         size_t nb = ((size_t)N * Dm / 8 + kThreads) / kThreads;
@@ -1694,15 +1694,10 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         else hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dyp, (int64_t)N * Dm, dy16);
         hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream,
                            (const __bf16 *)w16, Dm, K, wt16);
-        if ((rc = launch_zero_words(ws16 + U.byte0, 4, stream))) return rc;
-        if ((rc = check_launch("iota/narrow/transpose"))) return rc;
-        MotEmbedMixDesc g16;
-        du16_desc(g16, d, N, K);
-        g16.tokens = iota; g16.ids_a = (const int64_t *)iota;  // never read with bpt == 0
-        g16.tok_table = dy16; g16.byte_table = ws16 + U.byte0; g16.weight = wt16; g16.out = du16;
-        g16.workspace = ws16 + U.lin; g16.workspace_bytes = U.lin_bytes;
-        if ((rc = launch_embed_mix_linear_bf16(g16, stream))) return rc;
-        if ((rc = launch_widen(du16, (size_t)N * K, du, stream))) return rc;
+        if ((rc = check_launch("narrow/transpose"))) return rc;
+        // du[n][k] = sum_m dy16[n][m] * wt16[k][m], accumulated and written in fp32 (no bf16 round trip before the scatter)
+        if ((rc = launch_gemm_rows_bf16(dy16, Dm, N, wt16, Dm, Dm, K, du, K, false, nullptr, stream))) return rc;
+        (void)du16;
     } else {
     // 3. du = dy . W   (N x Dm) @ (Dm x K): both row-major as they are (nn.Linear keeps W as [Dm][K])
     if ((rc = launch_gemm_rows(dyp, Dm, N, (const float *)d.weight, K, Dm, K, du, K, false, stream))) return rc;
