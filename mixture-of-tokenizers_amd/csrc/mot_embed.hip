@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
             vec_t a[1][NCH], b[1][NCH];
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                a[0][i] = act[i] ? Elem<T>::widen(ar[u][i]) : (vec_t)(0.f);
+                a[0][i] = Elem<T>::widen(ar[u][i]);   // lanes past the row end hold a copy of the row's first chunk: kept out of the sums below, never stored
                 if (MODE == MOT_MIX_SUM) {
                     vec_t v = Elem<T>::widen(br[u][i]);
                     if (dual) v += Elem<T>::widen(br2[DUAL ? u : 0][i]);  // emb(padded) + emb(pulled), train_gpt.py:378
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
             if (A.norm_tok) {
                 float ss = 0.f;
 #pragma unroll
-                for (int i = 0; i < NCH; ++i) ss += sumsq(a[0][i]);
+                for (int i = 0; i < NCH; ++i) ss += act[i] ? sumsq(a[0][i]) : 0.f;
                 const float r = rms_scale(wave_sum(ss), Dm, A.eps);
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) a[0][i] *= r;

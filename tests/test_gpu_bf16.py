@@ -85,8 +85,14 @@ def test_bf16_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
     r = mot.embed_mix(dev(toks), dev(Et).bfloat16(), dev(Eb).bfloat16(), mode="sum", bpt=bpt, ttb=dev(tab), pull="left",
                       return_ids=True, **kw)
     np.testing.assert_array_equal(host(r.ids_pulled), pulled)
-    assert ulps(host(r.x.float()), orc.bf16_round(ref)).max() <= 1
-    assert (host(r.x.float()) == orc.bf16_round(ref)).mean() > 0.98     # almost always the same rounding
+    got = host(r.x.float())
+    # one bf16 step -- except where the output is what is left of two cancelling terms (token part + byte part): there the
+    # fp32 rounding of the rms factors (v_rsq_f32, <= 1 ulp, as a GPU rsqrt is) is no longer small against the result, so
+    # the bar is absolute, 2e-6 of the row's largest entry (a few fp32 ulps of the terms)
+    row_max = np.abs(ref).max(axis=-1, keepdims=True)
+    ok = (ulps(got, orc.bf16_round(ref)) <= 1) | (np.abs(got.astype(np.float64) - ref) <= 2e-6 * row_max)
+    assert ok.all()
+    assert (got == orc.bf16_round(ref)).mean() > 0.98     # almost always the same rounding
 
 
 def test_bf16_limits(mot):
