@@ -256,7 +256,7 @@ static int launch_gather_g(const void *ids_a, const void *ids_b, int ids_elem, i
                            int group, int64_t out_ld, uint32_t oor_flag, hipStream_t stream) {
     const int64_t per_block = kThreads / G;
     int64_t blocks = (n + per_block - 1) / per_block;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 128) blocks = 256 * 128;   // one row per lane group and pass: short dependent chains (id -> row), so many groups in flight
     if (ids_elem == 8)
         hipLaunchKernelGGL((gather_rows_kernel<G, int64_t, T>), dim3((unsigned)blocks), dim3(kThreads), 0, stream,
                            (const int64_t *)ids_a, (const int64_t *)ids_b, n, (const T *)table, rows, dim, rms, eps, scale, (T *)out, status, group, out_ld, oor_flag);
