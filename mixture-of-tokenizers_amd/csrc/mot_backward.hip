@@ -1209,8 +1209,14 @@ __device__ __forceinline__ void gemm_rows_body(const float *__restrict__ A_, int
     constexpr int LDA = 132, LDB = BT ? 132 : 128;
     __shared__ __attribute__((aligned(16))) float lA[2][16 * LDA], lB[2][16 * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
-    const int64_t j0 = (int64_t)blockIdx.x * 128;
-    const int k0 = blockIdx.y * 128;
+    // XCD-aware block order (1-D grid, workgroup ids round-robin over the 8 XCDs): an XCD walks all column blocks of a row panel
+    // back to back, so the panel of A is fetched into that XCD's L2 once instead of once per column block
+    const int64_t gx = (n + 127) / 128;
+    const int gy = (Nc + 127) / 128;
+    const int64_t bid = blockIdx.x, seq = bid >> 3, panel = (seq / gy) * 8 + (bid & 7);
+    if (panel >= gx) return;   // the grid is padded to whole groups of 8 panels
+    const int64_t j0 = panel * 128;
+    const int k0 = (int)(seq % gy) * 128;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     // acc is the MFMA accumulator of kFold reduction steps at a time; it is then folded into `sum` with vector adds and
     // restarted, so no fp32 summation chain is longer than 8 * kFold MFMA steps (blocked summation, like the reference's
@@ -1340,15 +1346,16 @@ int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int l
     if (n <= 0 || Nc <= 0) return MOT_OK;
     const int64_t gx = (n + 127) / 128;
     const int gy = (Nc + 127) / 128;
-    if (gx > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows: too many rows");
+    const int64_t blocks = (gx + 7) / 8 * 8 * gy;   // 1-D, see the block order in the kernel
+    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows: too many rows");
     for (int r0 = 0; r0 < R || r0 == 0; r0 += kGemmRowsPass) {
         const int rn = R - r0 < kGemmRowsPass ? R - r0 : kGemmRowsPass;
         const float *a = A_ + r0, *b = b_transposed ? B_ + r0 : B_ + (int64_t)r0 * ldb;
         if (b_transposed)
-            hipLaunchKernelGGL(gemm_rows_bt_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
+            hipLaunchKernelGGL(gemm_rows_bt_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
                                r0 ? nullptr : bias, r0 ? 1 : 0);
         else
-            hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
+            hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
                                r0 ? nullptr : bias, r0 ? 1 : 0);
         if (r0 + kGemmRowsPass >= R) break;
     }
