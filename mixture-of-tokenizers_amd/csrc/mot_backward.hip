@@ -425,6 +425,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
 
     float acc[NE], an[NE];   // the current run: gradient of the token's table row so far, its (normalised) table row
     float ra = 1.f;          // 1 / rms of that row
+    const float inv_dt = 1.0f / (float)A.Dt;
     int cur = -1;
     auto flush = [&]() {
         if (cur < 0 || (A.abl & 2)) return;
@@ -648,7 +649,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     m += dy[j] * y;
                 }
                 const float ry = rms_scale(wave_sum(ss), D, A.eps);
-                m = wave_sum(m) * ry / (float)D;       // mean(g * x), x = y * ry
+                m = wave_sum(m) * ry * (1.0f / (float)D);       // mean(g * x), x = y * ry   (a multiply, not an IEEE divide: <= 1 ulp)
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const float x = (an[j] * s_tok + (MODE == MOT_MIX_SUM ? bn[j] * s_byte : 0.f)) * ry;
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                 for (int j = 0; j < NE; ++j) dot += dy[j] * an[j];
                 ds_t += dot;
                 float mt = 0.f;
-                if (A.norm_tok) mt = wave_sum(dot * s_tok) / (float)A.Dt;
+                if (A.norm_tok) mt = wave_sum(dot * s_tok) * inv_dt;
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const float da = dy[j] * s_tok;
