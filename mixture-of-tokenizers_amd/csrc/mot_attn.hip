@@ -78,62 +78,66 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
         q0 = a;
         q1 = b;
     }
-    const float sqrt_hd = sqrtf((float)kHd);
-    float m = -FLT_MAX, l = 0.f, y0 = 0.f, y1 = 0.f;
+    const float inv_sqrt_hd = 1.0f / sqrtf((float)kHd);   // line 286 divides by sqrt(head_dim): kHd = 128, the product differs by <= 1 ulp
     // flat row r of the (T*bpt, H, hd) key/value memory = pos * H + hk; walked incrementally (one division per wave)
-    int64_t pos = t * A.bpt;
-    int hk = h;
+    int64_t pos0 = t * A.bpt;
+    int hk0 = h;
     if (A.layout == 0) {
         const int64_t r0 = ((int64_t)h * A.T + t) * A.bpt;
-        pos = r0 / A.H;
-        hk = (int)(r0 - pos * A.H);
+        pos0 = r0 / A.H;
+        hk0 = (int)(r0 - pos0 * A.H);
     }
-    // software pipeline: key c+1's row, rotary row and value are requested before key c's score chain (exp, max) runs;
-    // the rotary row is re-read only when the kv position changes (as_viewed walks H heads per position)
-    auto row_of = [&](int64_t p) {
+    auto advance = [&](int64_t &pos, int &hk) {
+        if (A.layout == 0) { if (++hk == A.H) { hk = 0; ++pos; } } else ++pos;
+    };
+    // lane c < bpt looks up the table row of key c once (the per-key loads below then start from a scalar row index instead
+    // of waiting for an id load each)
+    int rowv = 0;
+    if (lane < A.bpt) {
+        int64_t p = pos0 + lane;
+        if (A.layout == 0) p = (((int64_t)h * A.T + t) * A.bpt + lane) / A.H;
         int64_t row = p;
         if (A.ids) {
             row = A.ids[p];
             if ((uint64_t)row >= (uint64_t)A.rows) {
-                if (A.status && lane == 0) atomicOr(A.status, kStatusByteOor);
+                if (A.status) atomicOr(A.status, kStatusByteOor);
                 row = 0;
             }
         }
-        return row;
-    };
-    float k0n, k1n, v0n, v1n, ckn, skn;
-    {
-        const int64_t row = row_of(pos);
-        const float *kp = A.kt + row * HD + hk * kHd, *vp = A.vt + row * HD + hk * kHd;
-        k0n = kp[lane]; k1n = kp[64 + lane]; v0n = vp[lane]; v1n = vp[64 + lane];
-        ckn = A.cos_k[pos * 64 + lane]; skn = A.sin_k[pos * 64 + lane];
+        rowv = (int)row;
     }
-    for (int c = 0; c < A.bpt; ++c) {
-        const float k0 = k0n, k1 = k1n, v0 = v0n, v1 = v1n, ck = ckn, sk = skn;
-        if (c + 1 < A.bpt) {
-            const int64_t pos_prev = pos;
-            if (A.layout == 0) {
-                if (++hk == A.H) { hk = 0; ++pos; }
-            } else {
-                ++pos;
-            }
-            const int64_t row = row_of(pos);
-            const float *kp = A.kt + row * HD + hk * kHd, *vp = A.vt + row * HD + hk * kHd;
-            k0n = kp[lane]; k1n = kp[64 + lane]; v0n = vp[lane]; v1n = vp[64 + lane];
-            if (pos != pos_prev) { ckn = A.cos_k[pos * 64 + lane]; skn = A.sin_k[pos * 64 + lane]; }
+    // pass 1: scores, lane c keeps s_c; then the softmax over the bpt keys across lanes (one exp for all of them, line 287)
+    float sc = -FLT_MAX;
+    {
+        int64_t pos = pos0; int hk = hk0;
+        for (int c = 0; c < A.bpt; ++c) {
+            const float *kp = A.kt + (int64_t)__builtin_amdgcn_readlane(rowv, c) * HD + hk * kHd;
+            const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
+            const float s = wave_sum(q0 * ka + q1 * kb) * inv_sqrt_hd;
+            if (lane == c) sc = s;
+            advance(pos, hk);
         }
-        const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
-        const float s = wave_sum(q0 * ka + q1 * kb) / sqrt_hd;   // line 286
-        const float mn = fmaxf(m, s);
-        const float scale = expf(m - mn), p = expf(s - mn);
-        l = l * scale + p;
-        y0 = y0 * scale + p * v0;
-        y1 = y1 * scale + p * v1;
-        m = mn;
+    }
+    const float mx = wave_max(sc);
+    float p = lane < A.bpt ? expf(sc - mx) : 0.f;
+    p /= wave_sum(p);
+    // pass 2: y = sum_c p_c v_c   (line 289)
+    float y0 = 0.f, y1 = 0.f;
+    {
+        int hk = hk0;
+        int64_t pos = pos0;
+        for (int c = 0; c < A.bpt; ++c) {
+            const float *vp = A.vt + (int64_t)__builtin_amdgcn_readlane(rowv, c) * HD + hk * kHd;
+            const float pc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), c));
+            y0 += pc * vp[lane];
+            y1 += pc * vp[64 + lane];
+            advance(pos, hk);
+        }
     }
     float *yp = A.y + t * HD + h * kHd;
-    yp[lane] = y0 / l;
-    yp[64 + lane] = y1 / l;
+    yp[lane] = y0;
+    yp[64 + lane] = y1;
 }
 
 __global__ __launch_bounds__(kThreads) void iota32_kernel(int32_t *p, int64_t n) {
@@ -302,17 +306,22 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     auto advance = [&](int64_t &pos, int &hk) {
         if (A.layout == 0) { if (++hk == A.H) { hk = 0; ++pos; } } else ++pos;
     };
-    auto row_of = [&](int64_t p) {
+    // lane c < bpt looks up the table row of key c once; the passes below start from that scalar row index
+    int rowv = 0;
+    if (lane < A.bpt) {
+        int64_t p = pos0 + lane;
+        if (A.layout == 0) p = (((int64_t)h * A.T + t) * A.bpt + lane) / A.H;
         int64_t row = A.ids[p];
         if ((uint64_t)row >= (uint64_t)A.rows) row = 0;   // flagged by the forward
-        return row;
-    };
+        rowv = (int)row;
+    }
+    auto row_at = [&](int c) { return (int64_t)__builtin_amdgcn_readlane(rowv, c); };
     // pass 1: scores; lane c keeps s_c
     float sc = -FLT_MAX;
     {
         int64_t pos = pos0; int hk = hk0;
         for (int c = 0; c < A.bpt; ++c) {
-            const float *kp = A.kn + row_of(pos) * HD + hk * kHd;
+            const float *kp = A.kn + row_at(c) * HD + hk * kHd;
             const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
             const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
             const float s = wave_sum(q0 * ka + q1 * kb) * inv_sqrt;
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     {
         int64_t pos = pos0; int hk = hk0;
         for (int c = 0; c < A.bpt; ++c) {
-            const float *vp = A.vpre + row_of(pos) * HD + hk * kHd;
+            const float *vp = A.vpre + row_at(c) * HD + hk * kHd;
             const float v0 = lam * vp[lane], v1 = lam * vp[64 + lane];
             const float d = wave_sum(dy0 * v0 + dy1 * v1);
             if (lane == c) dp = d;
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     {
         int64_t pos = pos0; int hk = hk0;
         for (int c = 0; c < A.bpt; ++c) {
-            const float *kp = A.kn + row_of(pos) * HD + hk * kHd;
+            const float *kp = A.kn + row_at(c) * HD + hk * kHd;
             const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
             const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
             const float dsc = __shfl(ds, c, 64);
