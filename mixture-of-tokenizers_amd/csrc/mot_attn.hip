@@ -140,25 +140,10 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
     yp[64 + lane] = y1;
 }
 
-__global__ __launch_bounds__(kThreads) void iota32_kernel(int32_t *p, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) p[i] = (int32_t)i;
-}
 
 // ------------------------------------------------------------------------------------------ host
-// workspace, in floats: [q: T*HD][y: T*HD][kt: R*HD][vt: R*HD][xkv: dual ? T*bpt*D : 0][iota: max(T, R) int32][byte0: 4][lin: ...]
-struct AttnLayout { size_t q, y, kt, vt, xkv, xq, iota, byte0, lin, lin_floats, total; int64_t R; };
-
-static void dense_desc(MotEmbedMixDesc &g, const int32_t *iota, const float *byte0, const void *rows, int64_t n_rows_tab, int64_t n, int K,
-                       const void *weight, int Dm, void *out, uint32_t *status, void *ws, size_t ws_bytes) {
-    memset(&g, 0, sizeof(g));
-    g.struct_size = sizeof(g); g.dtype = MOT_F32;
-    g.n_rows = 1; g.tokens_per_row = n; g.bpt = 0; g.mode = MOT_MIX_CONCAT_LINEAR;
-    g.tokens = iota; g.id_source = MOT_IDS_GIVEN; g.ids_a = (const int64_t *)iota;  // never read with bpt == 0
-    g.tok_table = rows; g.tok_rows = n_rows_tab; g.tok_dim = K;
-    g.byte_table = byte0; g.byte_rows = 1; g.byte_dim = 4;
-    g.weight = weight; g.model_dim = Dm; g.out = out; g.status = status;
-    g.workspace = ws; g.workspace_bytes = ws_bytes;
-}
+// workspace, in floats: [q: T*HD][y: T*HD][kt: R*HD][vt: R*HD][xkv: R*D (dual: R = T*bpt)][xq: D > HD ? T*D : 0]
+struct AttnLayout { size_t q, y, kt, vt, xkv, xq, total; int64_t R; };
 
 static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     AttnLayout L;
@@ -168,24 +153,15 @@ static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
     L.q = take(T * HD); L.y = take(T * HD); L.kt = take((size_t)L.R * HD); L.vt = take((size_t)L.R * HD);
-    L.xkv = take(dual ? T * d.bpt * D : 0);
+    L.xkv = take(dual ? T * d.bpt * D : (size_t)L.R * D);   // the (normalised) key/value source rows: per kv position, or per byte-table row
     L.xq = take(D > HD ? T * D : 0);   // the gathered query rows live in y's place until the attention writes y
-    L.iota = take(T > (size_t)L.R ? T : (size_t)L.R); L.byte0 = take(4);
-    MotEmbedMixDesc g;     // the widest of the GEMMs decides the transposed-weight scratch
-    const int64_t max_rows = d.tok_rows > L.R ? d.tok_rows : L.R;   // the normalising GEMMs keep a per-row rms table in the scratch
-    dense_desc(g, nullptr, nullptr, nullptr, max_rows, 1, (int)D, nullptr, (int)HD, nullptr, nullptr, nullptr, 0);
-    g.norm_tok = 1;
-    size_t a = embed_mix_linear_workspace_bytes(g);
-    dense_desc(g, nullptr, nullptr, nullptr, max_rows, 1, (int)HD, nullptr, (int)D, nullptr, nullptr, nullptr, 0);
-    g.norm_tok = 1;
-    size_t b = embed_mix_linear_workspace_bytes(g);
-    L.lin_floats = ((a > b ? a : b) + 3) / 4;
-    L.lin = take(L.lin_floats);
     L.total = o;
     return L;
 }
 
 size_t cross_attn_workspace_bytes(const MotCrossAttnDesc &d) { return attn_layout(d).total * 4; }
+
+__global__ void rows_norm_kernel(const float *__restrict__ table, int64_t rows, int D, int norm, float eps, float *__restrict__ xn);
 
 int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     const int64_t T = d.n_tokens;
@@ -194,9 +170,7 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     if (!d.workspace || d.workspace_bytes < L.total * 4)
         return set_error(MOT_EWORKSPACE, "cross_attn: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
     float *ws = (float *)d.workspace;
-    float *q = ws + L.q, *y = ws + L.y, *kt = ws + L.kt, *vt = ws + L.vt, *xkv = ws + L.xkv, *byte0 = ws + L.byte0, *lin = ws + L.lin;
-    int32_t *iota = (int32_t *)(ws + L.iota);
-    const size_t lin_bytes = L.lin_floats * 4;
+    float *q = ws + L.q, *y = ws + L.y, *kt = ws + L.kt, *vt = ws + L.vt, *xkv = ws + L.xkv;
     const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
     const bool dual = d.ids_b != nullptr;
     if (d.saved_qy) {   // kept for the backward
@@ -208,34 +182,27 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
         kt = (float *)d.kv_tables;
         vt = kt + (size_t)L.R * HD;
     }
-    const int64_t n_iota = T > L.R ? T : L.R;
     int rc;
-    hipLaunchKernelGGL(iota32_kernel, dim3(256), dim3(kThreads), 0, stream, iota, n_iota);
-    if ((rc = check_launch("iota32_kernel"))) return rc;
-    if ((rc = launch_zero_words(byte0, 4, stream))) return rc;
-    MotEmbedMixDesc g;
     // 1. q = W_q norm?(E_t[tok])          (train_gpt.py:348-377 + 277): seam gather, then the plain dense MFMA kernel
     float *xq = D > HD ? ws + L.xq : y;
     if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, (int)D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
         return rc;
     if ((rc = launch_gemm_rows(xq, (int)D, T, (const float *)d.q_w, (int)D, (int)D, (int)HD, q, (int)HD, true, stream))) return rc;
     // 2. key/value rows: per byte-table row, or per kv position when the embedding is norm(E[a] + E[b])
-    const void *kv_rows = d.byte_table;
-    int kv_norm = d.norm_byte;
+    const int kv_norm = d.norm_byte;
     if (dual) {
         if ((rc = launch_gather_rows(d.ids_a, d.ids_b, 8, T * d.bpt, d.byte_table, d.byte_rows, D, d.norm_byte, eps, nullptr, xkv, d.status,
                                      MOT_F32, stream))) return rc;
-        kv_rows = xkv;
-        kv_norm = 0;
     }
     if (!(kv_cached && d.kv_tables_ready)) {
         const float *kv_w = (const float *)d.kv_w;
-        dense_desc(g, iota, byte0, kv_rows, L.R, L.R, D, kv_w, HD, kt, d.status, lin, lin_bytes);
-        g.norm_tok = kv_norm; g.eps = eps;
-        if ((rc = launch_embed_mix_linear(g, stream))) return rc;
-        dense_desc(g, iota, byte0, kv_rows, L.R, L.R, D, kv_w + (size_t)HD * D, HD, vt, d.status, lin, lin_bytes);
-        g.norm_tok = kv_norm; g.eps = eps;
-        if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+        if (!dual) {   // rows of the byte table, normalised once (458 rows): the plain dense kernel then projects them
+            hipLaunchKernelGGL(rows_norm_kernel, dim3((unsigned)((L.R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, L.R,
+                               (int)D, kv_norm, eps, xkv);
+            if ((rc = check_launch("rows_norm_kernel"))) return rc;
+        }
+        if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w, (int)D, (int)D, (int)HD, kt, (int)HD, true, stream))) return rc;
+        if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w + (size_t)HD * D, (int)D, (int)D, (int)HD, vt, (int)HD, true, stream))) return rc;
         const int64_t kvw = L.R * H;
         hipLaunchKernelGGL(kv_finish_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kt, vt, L.R, H,
                            d.lambda_factor, eps);
@@ -451,15 +418,10 @@ __global__ __launch_bounds__(kThreads) void ids_to_i32_kernel(const int64_t *__r
     }
 }
 
-static int out_cols_pad(int n) {   // the column padding embed_mix_linear_kernel dispatches on (mot_linear.hip nt_of)
-    int p = (n + 127) / 128 * 128;
-    if (p > 512 && p <= 768) p = 768; else if (p > 768) p = 1024;
-    return p;
-}
 
 // workspace of the backward, in floats
 struct AttnBwdLayout {
-    size_t q, y, kpre, vpre, kn, vl, dy, dq, dkn_pos, dvl_pos, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, iota, byte0, wk, lin, lin_floats, emb, emb_bytes, total;
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, dkn_pos, dvl_pos, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, emb, emb_bytes, total;
 };
 static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
     memset(&e, 0, sizeof(e));
@@ -475,15 +437,7 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     L.q = take(T * HD); L.y = take(T * HD); L.kpre = take(R * HD); L.vpre = take(R * HD); L.kn = take(R * HD); L.vl = take(R * HD);
     L.dy = take(T * HD); L.dq = take(T * HD); L.dkn_pos = take(P * HD); L.dvl_pos = take(P * HD);
     L.dkn_tab = take(R * HD); L.dvl_tab = take(R * HD); L.dkv = take(R * 2 * HD); L.xkv = take(R * D); L.dxkv = take(R * D);
-    L.xq = take(T * D); L.dxq = take(T * D); L.ids32 = take(P); L.iota = take(T > R ? T : R); L.byte0 = take(4);
-    const size_t kc = (2 * HD + 15) / 16 * 16 > (D + 15) / 16 * 16 ? (2 * HD + 15) / 16 * 16 : (D + 15) / 16 * 16;
-    L.wk = take(kc * (size_t)out_cols_pad((int)(HD > D ? HD : D)));
-    MotEmbedMixDesc g;
-    const int64_t max_rows = d.tok_rows > (int64_t)R ? d.tok_rows : (int64_t)R;
-    dense_desc(g, nullptr, nullptr, nullptr, max_rows, 1, (int)D, nullptr, (int)HD, nullptr, nullptr, nullptr, 0);
-    g.norm_tok = 1;
-    L.lin_floats = (embed_mix_linear_workspace_bytes(g) + 3) / 4;
-    L.lin = take(L.lin_floats);
+    L.xq = take(T * D); L.dxq = take(T * D); L.ids32 = take(P);
     MotEmbedMixDesc e;   // the three embedding-backward calls share one scratch: the largest
     noop_bwd_desc(e, nullptr, (int64_t)T, nullptr, d.tok_rows, (int)D, d.norm_tok, 0.f, nullptr);
     size_t a = embed_mix_bwd_workspace_bytes(e);
@@ -511,21 +465,17 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     float *ws = (float *)d.workspace;
     float *q = ws + L.q, *y = ws + L.y, *kpre = ws + L.kpre, *vpre = ws + L.vpre, *kn = ws + L.kn, *vl = ws + L.vl, *dy = ws + L.dy, *dq = ws + L.dq;
     float *dkn_pos = ws + L.dkn_pos, *dvl_pos = ws + L.dvl_pos, *dkn_tab = ws + L.dkn_tab, *dvl_tab = ws + L.dvl_tab, *dkv = ws + L.dkv;
-    float *xkv = ws + L.xkv, *dxkv = ws + L.dxkv, *xq = ws + L.xq, *dxq = ws + L.dxq, *byte0 = ws + L.byte0, *lin = ws + L.lin;
-    int32_t *ids32 = (int32_t *)(ws + L.ids32), *iota = (int32_t *)(ws + L.iota);
+    float *xkv = ws + L.xkv, *dxkv = ws + L.dxkv, *xq = ws + L.xq, *dxq = ws + L.dxq;
+    int32_t *ids32 = (int32_t *)(ws + L.ids32);
     void *emb_ws = ws + L.emb;
-    const size_t lin_bytes = L.lin_floats * 4;
     const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
     const float *g_out = (const float *)gr.grad_out;
     int rc;
-    hipLaunchKernelGGL(iota32_kernel, dim3(256), dim3(kThreads), 0, stream, iota, T > R ? T : R);
     hipLaunchKernelGGL(ids_to_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, d.ids_a, P, R, ids32);
-    if ((rc = check_launch("iota32 / ids_to_i32"))) return rc;
-    if ((rc = launch_zero_words(byte0, 4, stream))) return rc;
+    if ((rc = check_launch("ids_to_i32"))) return rc;
     if ((rc = launch_zero_words(dkn_tab, (int64_t)R * HD, stream))) return rc;
     if ((rc = launch_zero_words(dvl_tab, (int64_t)R * HD, stream))) return rc;
     // ---- forward recompute (the queries and the attention output come from the forward when it kept them)
-    MotEmbedMixDesc g;
     bool have_xq = false;   // the gathered (normalised) token rows are already in xq
     if (d.saved_qy) {
         q = (float *)d.saved_qy;
@@ -536,12 +486,11 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         have_xq = true;
     }
     const float *kv_w = (const float *)d.kv_w;
-    dense_desc(g, iota, byte0, d.byte_table, R, R, D, kv_w, HD, kpre, d.status, lin, lin_bytes);
-    g.norm_tok = d.norm_byte; g.eps = eps;
-    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
-    dense_desc(g, iota, byte0, d.byte_table, R, R, D, kv_w + (size_t)HD * D, HD, vpre, d.status, lin, lin_bytes);
-    g.norm_tok = d.norm_byte; g.eps = eps;
-    if ((rc = launch_embed_mix_linear(g, stream))) return rc;
+    // the normalised byte-table rows (also the operand of dW_kv below), projected by the plain dense kernel
+    hipLaunchKernelGGL(rows_norm_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, R, D, d.norm_byte, eps, xkv);
+    if ((rc = check_launch("rows_norm_kernel"))) return rc;
+    if ((rc = launch_gemm_rows(xkv, D, R, kv_w, D, D, HD, kpre, HD, true, stream))) return rc;
+    if ((rc = launch_gemm_rows(xkv, D, R, kv_w + (size_t)HD * D, D, D, HD, vpre, HD, true, stream))) return rc;
     const int64_t kvw = R * H;
     hipLaunchKernelGGL(kv_norm_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kpre, vpre, R, H, d.lambda_factor, eps, kn, vl);
     if ((rc = check_launch("kv_norm_kernel"))) return rc;
@@ -577,9 +526,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     hipLaunchKernelGGL(kv_table_bwd_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, dkn_tab, dvl_tab, kpre, vpre, R, H,
                        d.lambda_factor, eps, dkv, gr.d_lambda);
     if ((rc = check_launch("kv_table_bwd_kernel"))) return rc;
-    // ---- kv_w and the byte table
-    hipLaunchKernelGGL(rows_norm_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, R, D, d.norm_byte, eps, xkv);
-    if ((rc = check_launch("rows_norm_kernel"))) return rc;
+    // ---- kv_w and the byte table (xkv: the normalised table rows built for the recompute above)
     if (gr.d_kv_w && (rc = launch_gemm_tn(dkv, 2 * HD, 2 * HD, xkv, D, D, R, (float *)gr.d_kv_w, D, stream))) return rc;
     if (gr.d_byte_table) {
         if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;   // kv_w as [2 HD, D]
