@@ -1417,27 +1417,15 @@ static int launch_widen(const void *src, size_t n, float *dst, hipStream_t strea
 
 // du = dy . W of the bf16 backward on the bf16 MFMA (what autograd does for bf16 parameters): dy rounded to bf16,
 // W^T as the [K, Dm] "weight" of the forward bf16 kernel in dense-row mode, du widened back for the scatter stage.
-// Scratch behind the fp32 layouts, in bytes: [dy16: N*Dm*2][wt16: K*Dm*2][du16: N*K*2][byte0: 16][kernel workspace].
-struct Du16Layout { size_t dy16, wt16, du16, byte0, dyT, uT, lin, lin_bytes, total; };
-static void du16_desc(MotEmbedMixDesc &g, const MotEmbedMixDesc &d, int64_t N, int K) {
-    memset(&g, 0, sizeof(g));
-    g.struct_size = sizeof(g); g.dtype = MOT_BF16;
-    g.n_rows = 1; g.tokens_per_row = N; g.bpt = 0; g.mode = MOT_MIX_CONCAT_LINEAR;
-    g.id_source = MOT_IDS_GIVEN;
-    g.tok_rows = N; g.tok_dim = d.model_dim; g.byte_rows = 1; g.byte_dim = 8;
-    g.model_dim = K; g.status = d.status;
-}
+// Scratch behind the fp32 layouts, in bytes: [dy16: N*Dm*2][wt16: K*Dm*2][dyT: N*Dm*2][uT: N*K*2].
+struct Du16Layout { size_t dy16, wt16, dyT, uT, total; };
 static Du16Layout du16_layout(const MotEmbedMixDesc &d) {
     Du16Layout U;
     const size_t N = (size_t)(d.n_rows * d.tokens_per_row), K = (size_t)d.tok_dim + (size_t)d.bpt * d.byte_dim, Dm = (size_t)d.model_dim;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
-    U.dy16 = take(N * Dm * 2); U.wt16 = take(K * Dm * 2); U.du16 = take(N * K * 2); U.byte0 = take(16);
+    U.dy16 = take(N * Dm * 2); U.wt16 = take(K * Dm * 2);
     U.dyT = take(N * Dm * 2); U.uT = take(N * K * 2);   // token-major -> token-minor copies for the dW GEMM
-    MotEmbedMixDesc g;
-    du16_desc(g, d, (int64_t)N, (int)K);
-    U.lin_bytes = embed_mix_linear_bf16_workspace_bytes(g);
-    U.lin = take(U.lin_bytes);
     U.total = o;
     return U;
 }
@@ -1575,7 +1563,6 @@ __global__ __launch_bounds__(kThreads) void transpose_bf16_kernel(const __bf16 *
 static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
     if (d.mode == MOT_MIX_CONCAT_LINEAR) {
-        // the du GEMM runs through launch_embed_mix_linear_ex with its own (small) scratch after ours
         return (lin_bwd_layout(d).total + (d.dtype == MOT_BF16 ? up_layout(d).total : 0)) * 4 + 256 + (du16_usable(d) ? du16_layout(d).total : 0);
     }
     return (bwd_rnorm_floats(d) + scatter_ws_ints(d)) * 4;
@@ -1695,7 +1682,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     if (w16) {
         // 3'. du on the bf16 MFMA: bf16(dy) rows x W^T on the dense bf16 kernel
         const Du16Layout U = du16_layout(d);
-        __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16), *wt16 = (__bf16 *)(ws16 + U.wt16), *du16 = (__bf16 *)(ws16 + U.du16);
+        __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16), *wt16 = (__bf16 *)(ws16 + U.wt16);
         size_t nb = ((size_t)N * Dm / 8 + kThreads) / kThreads;
         if (nb > 4096) nb = 4096;
         if (dy16p) dy16 = const_cast<__bf16 *>(dy16p);
@@ -1705,7 +1692,6 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         if ((rc = check_launch("narrow/transpose"))) return rc;
         // du[n][k] = sum_m dy16[n][m] * wt16[k][m], accumulated and written in fp32 (no bf16 round trip before the scatter)
         if ((rc = launch_gemm_rows_bf16(dy16, Dm, N, wt16, Dm, Dm, K, du, K, false, nullptr, stream))) return rc;
-        (void)du16;
     } else {
     // 3. du = dy . W   (N x Dm) @ (Dm x K): both row-major as they are (nn.Linear keeps W as [Dm][K])
     if ((rc = launch_gemm_rows(dyp, Dm, N, (const float *)d.weight, K, Dm, K, du, K, false, stream))) return rc;
