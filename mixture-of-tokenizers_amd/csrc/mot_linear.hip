@@ -4,6 +4,10 @@
 // tokens first, no bias, norms everywhere) and DigitMixinConcat after wte/dte
 // (mathblations/model.py:256-268, 323-327: digits first, bias, no norms).
 //
+// Two implementations live here.  The DEFAULT is composed from plain kernels (see "composed path" below: index kernels, seam
+// gather writing the concat operand, dense MFMA kernel, row norm; fp32 and bf16) and runs 20-30 % faster; the one-launch fused
+// tile kernel described next was the first path and is kept for learned embedding scalars and behind MOT_LIN_FUSED=1.
+//
 // This mode is a dense contraction over K = Dt + bpt*Db per token (~285 FLOP/B at
 // K = Dm = 768), so it is MFMA-bound, not HBM-bound, and uses the exact-fp32 matrix instruction
 // v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain: no precision is traded away).  What makes it a
