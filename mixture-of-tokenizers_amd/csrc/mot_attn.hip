@@ -225,11 +225,11 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
 //   forward recompute   q_pre = W_q xq;  k_pre, v_pre per byte-table row;  k_n = norm_head(k_pre);  y (attention)
 //   dW_p += g^T y                      gemm_tn            dy = g W_p            dense GEMM (prebuilt k-major operand)
 //   cross_attn_bwd_kernel, one wave per (token, head): softmax weights p_c across lanes (lane c holds key c),
-//       dV_l[r] = p_c dy           -> dvl_pos  [T*bpt, HD]   (flat row r = pos*H + head: each written by exactly one query)
-//       dk_n[r] = rope^T(ds_c q_r) -> dkn_pos  [T*bpt, HD]
+//       keeps p_c, ds_c [T, H, bpt] and the rotated queries [T, HD]; per key slot (flat row r = pos*H + head, owned by exactly one query)
+//       dV_l[r] = p_c dy,  dk_n[r] = rope^T(ds_c q_r)  -- formed and summed per byte id by attn_kv_rows_bwd_kernel, never stored
 //       dq_pre  = norm_head^T(rope^T(sum_c ds_c k_r))        -> dq [T, HD]
-//   per byte-table row: dkn_tab / dvl_tab = sum of the position rows with that id  -- exactly an embedding backward
-//       (launch_embed_mix_bwd, NOOP, "tokens" = byte ids, table rows = the K/V table rows)
+//   per byte-table row: dkn_tab / dvl_tab = sum of those slot gradients over the kv positions with that id (positions grouped by
+//       launch_group_positions, attn_kv_rows_bwd_kernel)
 //   kv_table_bwd_kernel: d lambda, d v_pre = lambda dV_l, d k_pre = norm_head^T(dk_n)   -> dkv [R, 2 HD]
 //   dW_kv += dkv^T xkv_tab (gemm_tn, R rows);  dxkv_tab = dkv W_kv (dense GEMM);  byte_rows_bwd_kernel: norm^T, d_byte += (rows ARE table rows)
 //   dW_q += dq^T xq (gemm_tn);  dxq = dq W_q (dense GEMM);  token-table gradient = launch_embed_mix_bwd (NOOP, norm_tok) on dxq
@@ -243,7 +243,9 @@ struct AttnBwdArgs {
     int bpt, H, layout;
     const float *cos_q, *sin_q, *cos_k, *sin_k;
     float eps;
-    float *dq, *dkn_pos, *dvl_pos;
+    float *dq;
+    float *pw, *dsw;   // [T, H, bpt]: softmax weight and score gradient of every (token, head, key)
+    float *qrot;       // [T, HD]: the normalised, rotated queries
 };
 
 __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdArgs A) {
@@ -308,15 +310,18 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
             const float v0 = lam * vp[lane], v1 = lam * vp[64 + lane];
             const float d = wave_sum(dy0 * v0 + dy1 * v1);
             if (lane == c) dp = d;
-            const float pc = __shfl(p, c, 64);
-            float *o = A.dvl_pos + (pos * A.H + hk) * (int64_t)kHd;
-            o[lane] = pc * dy0;
-            o[64 + lane] = pc * dy1;
             advance(pos, hk);
         }
     }
     const float dot = wave_sum(p * dp);
     const float ds = p * (dp - dot) * inv_sqrt;   // lane c
+    // what the per-table-row sums need of this (token, head): p_c and ds_c of its keys, and its rotated query
+    if (lane < A.bpt) {
+        A.pw[w * A.bpt + lane] = p;
+        A.dsw[w * A.bpt + lane] = ds;
+    }
+    A.qrot[t * HD + h * kHd + lane] = q0;
+    A.qrot[t * HD + h * kHd + 64 + lane] = q1;
     // pass 3: dq_r += ds_c k_r;  dk_n = rope^T(ds_c q_r)
     float dq0 = 0.f, dq1 = 0.f;
     {
@@ -328,10 +333,6 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
             const float dsc = __shfl(ds, c, 64);
             dq0 += dsc * ka;
             dq1 += dsc * kb;
-            const float g0 = dsc * q0, g1 = dsc * q1;             // d k_r
-            float *o = A.dkn_pos + (pos * A.H + hk) * (int64_t)kHd;
-            o[lane] = g0 * ck - g1 * sk;                            // rope^T
-            o[64 + lane] = g0 * sk + g1 * ck;
             advance(pos, hk);
         }
     }
@@ -341,6 +342,67 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     float *o = A.dq + t * HD + h * kHd;
     o[lane] = rq * (dn0 - qn0 * m);
     o[64 + lane] = rq * (dn1 - qn1 * m);
+}
+
+// Gradients of the per-row key / value tables: dkn_tab[r] = sum over the kv positions with byte id r of rope^T(ds * q_rot),
+// dvl_tab[r] = sum of p * dy -- an embedding backward whose "gradient rows" are never written: positions come grouped by byte
+// id (launch_group_positions), a wave walks a stretch of that order for ONE head slice, rebuilds each position's slice from
+// the query that owns it (p, ds: one scalar each; dy and q_rot: 512 bytes each, all of it L2 / Infinity Cache resident) and
+// keeps the running sums of the current id in registers.  (The first version wrote the two [T*bpt, HD] position arrays,
+// 6.4 GB, and read them back in two embedding-backward calls.)
+struct AttnRowsArgs {
+    const float *pw, *dsw, *dy, *qrot, *cos_k, *sin_k;
+    const int32_t *pos_sorted, *id_sorted;
+    int64_t P, T;
+    int bpt, H, layout;
+    float *dkn_tab, *dvl_tab;
+};
+constexpr int kRowsSeg = 256;   // sorted positions per wave
+__global__ __launch_bounds__(kThreads) void attn_kv_rows_bwd_kernel(const AttnRowsArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int hk = blockIdx.y;
+    const int HD = A.H * kHd;
+    const int64_t s_begin = w * kRowsSeg, s_end = min(A.P, s_begin + kRowsSeg);
+    float dv0 = 0.f, dv1 = 0.f, dk0 = 0.f, dk1 = 0.f;
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+        float *ok = A.dkn_tab + (int64_t)cur * HD + hk * kHd, *ov = A.dvl_tab + (int64_t)cur * HD + hk * kHd;
+        atomicAdd(ok + lane, dk0); atomicAdd(ok + 64 + lane, dk1);
+        atomicAdd(ov + lane, dv0); atomicAdd(ov + 64 + lane, dv1);
+    };
+    for (int64_t s0 = s_begin; s0 < s_end; s0 += 64) {
+        const int cnt = (int)min((int64_t)64, s_end - s0);
+        int vpos = 0, vid = 0;
+        if (lane < cnt) { vpos = A.pos_sorted[s0 + lane]; vid = A.id_sorted[s0 + lane]; }
+        for (int k = 0; k < cnt; ++k) {
+            const int64_t pos = __builtin_amdgcn_readlane(vpos, k);
+            const int id = __builtin_amdgcn_readlane(vid, k);
+            if (id != cur) { flush(); cur = id; dv0 = dv1 = dk0 = dk1 = 0.f; }
+            // the query (tq, hq) that owns key slot (pos, hk), and which of its keys this is
+            int64_t tq; int hq, c;
+            if (A.layout == 0) {
+                const int64_t r = pos * A.H + hk, qi = r / A.bpt;
+                c = (int)(r - qi * A.bpt);
+                hq = (int)(qi / A.T);
+                tq = qi - (int64_t)hq * A.T;
+            } else {
+                tq = pos / A.bpt;
+                c = (int)(pos - tq * A.bpt);
+                hq = hk;
+            }
+            const int64_t sidx = (tq * A.H + hq) * A.bpt + c, row = tq * HD + hq * kHd;
+            const float p = A.pw[sidx], ds = A.dsw[sidx];
+            const float ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            dv0 += p * A.dy[row + lane];
+            dv1 += p * A.dy[row + 64 + lane];
+            const float g0 = ds * A.qrot[row + lane], g1 = ds * A.qrot[row + 64 + lane];   // d k_r
+            dk0 += g0 * ck - g1 * sk;                                                        // rope^T
+            dk1 += g0 * sk + g1 * ck;
+        }
+    }
+    flush();
 }
 
 // k_n = norm_head(k_pre), v_l = lambda v_pre    (the forward's kv_finish, out of place)
@@ -421,7 +483,7 @@ __global__ __launch_bounds__(kThreads) void ids_to_i32_kernel(const int64_t *__r
 
 // workspace of the backward, in floats
 struct AttnBwdLayout {
-    size_t q, y, kpre, vpre, kn, vl, dy, dq, dkn_pos, dvl_pos, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, emb, emb_bytes, total;
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, emb, emb_bytes, total;
 };
 static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
     memset(&e, 0, sizeof(e));
@@ -435,14 +497,13 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
     L.q = take(T * HD); L.y = take(T * HD); L.kpre = take(R * HD); L.vpre = take(R * HD); L.kn = take(R * HD); L.vl = take(R * HD);
-    L.dy = take(T * HD); L.dq = take(T * HD); L.dkn_pos = take(P * HD); L.dvl_pos = take(P * HD);
+    L.dy = take(T * HD); L.dq = take(T * HD); L.pw = take(P * d.n_heads); L.dsw = take(P * d.n_heads); L.qrot = take(T * HD);
+    L.grp = take(group_positions_ws_ints((int64_t)P, (int64_t)R));   // byte ids of the kv positions, grouped
     L.dkn_tab = take(R * HD); L.dvl_tab = take(R * HD); L.dkv = take(R * 2 * HD); L.xkv = take(R * D); L.dxkv = take(R * D);
     L.xq = take(T * D); L.dxq = take(T * D); L.ids32 = take(P);
-    MotEmbedMixDesc e;   // the three embedding-backward calls share one scratch: the largest
+    MotEmbedMixDesc e;   // scratch of the token-table embedding backward
     noop_bwd_desc(e, nullptr, (int64_t)T, nullptr, d.tok_rows, (int)D, d.norm_tok, 0.f, nullptr);
-    size_t a = embed_mix_bwd_workspace_bytes(e);
-    noop_bwd_desc(e, nullptr, (int64_t)P, nullptr, (int64_t)R, (int)HD, 0, 0.f, nullptr);
-    size_t b = embed_mix_bwd_workspace_bytes(e);
+    size_t a = embed_mix_bwd_workspace_bytes(e), b = 0;
     L.emb_bytes = a > b ? a : b;
     L.emb = take((L.emb_bytes + 3) / 4);
     L.total = o;
@@ -464,7 +525,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         return set_error(MOT_EWORKSPACE, "cross_attn_bwd: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
     float *ws = (float *)d.workspace;
     float *q = ws + L.q, *y = ws + L.y, *kpre = ws + L.kpre, *vpre = ws + L.vpre, *kn = ws + L.kn, *vl = ws + L.vl, *dy = ws + L.dy, *dq = ws + L.dq;
-    float *dkn_pos = ws + L.dkn_pos, *dvl_pos = ws + L.dvl_pos, *dkn_tab = ws + L.dkn_tab, *dvl_tab = ws + L.dvl_tab, *dkv = ws + L.dkv;
+    float *pw = ws + L.pw, *dsw = ws + L.dsw, *qrot = ws + L.qrot, *dkn_tab = ws + L.dkn_tab, *dvl_tab = ws + L.dvl_tab, *dkv = ws + L.dkv;
     float *xkv = ws + L.xkv, *dxkv = ws + L.dxkv, *xq = ws + L.xq, *dxq = ws + L.dxq;
     int32_t *ids32 = (int32_t *)(ws + L.ids32);
     void *emb_ws = ws + L.emb;
@@ -509,20 +570,25 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     AttnBwdArgs B;
     B.q_pre = q; B.dy = dy; B.kn = kn; B.vpre = vpre; B.lambda = d.lambda_factor; B.ids = d.ids_a; B.rows = R; B.T = T; B.bpt = d.bpt; B.H = H;
     B.layout = d.head_layout; B.cos_q = d.cos_q; B.sin_q = d.sin_q; B.cos_k = d.cos_k; B.sin_k = d.sin_k; B.eps = eps;
-    B.dq = dq; B.dkn_pos = dkn_pos; B.dvl_pos = dvl_pos;
+    B.dq = dq; B.pw = pw; B.dsw = dsw; B.qrot = qrot;
     hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
     if ((rc = check_launch("cross_attn_bwd_kernel"))) return rc;
-    // ---- per byte-table row: sum the position rows of every id (an embedding backward with "tokens" = byte ids)
+    // ---- per byte-table row: the sums over the kv positions of every byte id, from the grouped positions
+    {
+        const int32_t *pos_sorted, *id_sorted;
+        if ((rc = launch_group_positions(ids32, P, R, (int32_t *)(ws + L.grp), &pos_sorted, &id_sorted, nullptr, stream))) return rc;
+        AttnRowsArgs Rw;
+        Rw.pw = pw; Rw.dsw = dsw; Rw.dy = dy; Rw.qrot = qrot; Rw.cos_k = d.cos_k; Rw.sin_k = d.sin_k;
+        Rw.pos_sorted = pos_sorted; Rw.id_sorted = id_sorted; Rw.P = P; Rw.T = T; Rw.bpt = d.bpt; Rw.H = H; Rw.layout = d.head_layout;
+        Rw.dkn_tab = dkn_tab; Rw.dvl_tab = dvl_tab;
+        const int64_t nw = (P + kRowsSeg - 1) / kRowsSeg;
+        hipLaunchKernelGGL(attn_kv_rows_bwd_kernel, dim3((unsigned)((nw + kWaves - 1) / kWaves), (unsigned)H), dim3(kThreads), 0, stream, Rw);
+        if ((rc = check_launch("attn_kv_rows_bwd_kernel"))) return rc;
+    }
     MotEmbedMixDesc ed;
     MotEmbedMixGrads eg;
     memset(&eg, 0, sizeof(eg));
     eg.struct_size = sizeof(eg);
-    noop_bwd_desc(ed, ids32, P, kn, R, HD, 0, eps, d.status);
-    ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
-    eg.grad_out = dkn_pos; eg.d_tok_table = dkn_tab;
-    if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
-    eg.grad_out = dvl_pos; eg.d_tok_table = dvl_tab;
-    if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
     hipLaunchKernelGGL(kv_table_bwd_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, dkn_tab, dvl_tab, kpre, vpre, R, H,
                        d.lambda_factor, eps, dkv, gr.d_lambda);
     if ((rc = check_launch("kv_table_bwd_kernel"))) return rc;

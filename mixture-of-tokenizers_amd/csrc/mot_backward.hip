@@ -951,6 +951,34 @@ static int dispatch_ne(const BwdArgs &A, size_t lds, hipStream_t stream) {
 // scatter stage shared by all modes: sort the positions by token id, then embed_mix_bwd_kernel.
 // `ws_ints` = [counts: tok_rows][starts: tok_rows][rank: N][pos_sorted: N][tok_sorted: N] (int32).
 // ------------------------------------------------------------------------------------------
+// The counting sort by itself: positions 0..n-1 grouped by ids[position] (clamped into [0, rows)); `ws_ints` holds
+// group_positions_ws_ints(n, rows) int32.  *pos_sorted / *id_sorted point into it.
+size_t group_positions_ws_ints(int64_t n, int64_t rows) { return 2 * (size_t)rows + 3 * (size_t)n; }
+int launch_group_positions(const int32_t *ids, int64_t n, int64_t rows, int32_t *ws_ints, const int32_t **pos_sorted_out, const int32_t **id_sorted_out,
+                           uint32_t *status, hipStream_t stream) {
+    if (rows >= (1 << 21) - 1) return set_error(MOT_EUNSUPPORTED, "group_positions: %lld rows (>= 2^21 - 1) are not built", (long long)rows);
+    int32_t *counts = ws_ints, *starts = counts + rows, *rank = starts + rows, *pos_sorted = rank + n, *id_sorted = pos_sorted + n;
+    int rc;
+    if ((rc = launch_zero_words(counts, rows, stream))) return rc;
+    const int rank_chunk = n >= 256 * 2048 ? 2048 : 512;
+    const int64_t rb = (n + rank_chunk - 1) / rank_chunk;
+    int64_t pb = (n + kThreads - 1) / kThreads;
+    if (pb > 2048) pb = 2048;
+    if (rb > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "group_positions: too many positions");
+    if (n > 0) {
+        if (rank_chunk == 2048)
+            hipLaunchKernelGGL(bwd_rank_kernel<2048>, dim3((unsigned)rb), dim3(kRankThreads), 0, stream, ids, n, rows, counts, rank, status);
+        else
+            hipLaunchKernelGGL(bwd_rank_kernel<512>, dim3((unsigned)rb), dim3(kRankThreads), 0, stream, ids, n, rows, counts, rank, status);
+        hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)((rows + 1023) / 1024)), dim3(1024), 0, stream, counts, rows, starts);
+        hipLaunchKernelGGL(bwd_place_kernel, dim3((unsigned)pb), dim3(kThreads), 0, stream, ids, n, rows, starts, rank, pos_sorted, id_sorted);
+        if ((rc = check_launch("group_positions kernels"))) return rc;
+    }
+    *pos_sorted_out = pos_sorted;
+    *id_sorted_out = id_sorted;
+    return MOT_OK;
+}
+
 static size_t scatter_ws_ints(const MotEmbedMixDesc &d) { return 2 * (size_t)d.tok_rows + 3 * (size_t)(d.n_rows * d.tokens_per_row); }
 
 template <int MODE>
@@ -964,29 +992,10 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
         return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: token tables of %lld rows (>= 2^21 - 1) are not built", (long long)d.tok_rows);
     const bool full = full_layout<MODE>(A);
     size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
-    {
-        int32_t *counts = ws_ints, *starts = counts + d.tok_rows, *rank = starts + d.tok_rows, *pos_sorted = rank + A.n_tokens,
-                *tok_sorted = pos_sorted + A.n_tokens;
-        if ((rc = launch_zero_words(counts, d.tok_rows, stream))) return rc;
-        const int rank_chunk = A.n_tokens >= 256 * 2048 ? 2048 : 512;
-        const int64_t rb = (A.n_tokens + rank_chunk - 1) / rank_chunk;
-        int64_t pb = (A.n_tokens + kThreads - 1) / kThreads;
-        if (pb > 2048) pb = 2048;
-        if (rb > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: too many positions");
-        if (rank_chunk == 2048)
-            hipLaunchKernelGGL(bwd_rank_kernel<2048>, dim3((unsigned)rb), dim3(kRankThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts, rank, A.status);
-        else
-            hipLaunchKernelGGL(bwd_rank_kernel<512>, dim3((unsigned)rb), dim3(kRankThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, counts, rank, A.status);
-        hipLaunchKernelGGL(bwd_scan_kernel, dim3((unsigned)((A.tok_rows + 1023) / 1024)), dim3(1024), 0, stream, counts, A.tok_rows, starts);
-        hipLaunchKernelGGL(bwd_place_kernel, dim3((unsigned)pb), dim3(kThreads), 0, stream, A.tokens, A.n_tokens, A.tok_rows, starts, rank,
-                           pos_sorted, tok_sorted);
-        if ((rc = check_launch("embed_mix_bwd sort kernels"))) return rc;
-        A.pos_sorted = pos_sorted;
-        A.tok_sorted = tok_sorted;
+    if ((rc = launch_group_positions(A.tokens, A.n_tokens, A.tok_rows, ws_ints, &A.pos_sorted, &A.tok_sorted, A.status, stream))) return rc;
 #ifdef MOT_DEV_ABLATION
-        if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
+    if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
 #endif
-    }
     A.priv_lo = 0; A.priv_hi0 = (int)d.byte_rows; A.priv_rows = 0;
     if (MODE != MOT_MIX_NOOP) {
         // as many byte-table rows as 150 KiB of LDS hold at 8 bytes per element; when not all fit, the last 32 rows

@@ -51,6 +51,10 @@ int launch_embed_mix_linear_composed(const MotEmbedMixDesc &d, hipStream_t strea
 int launch_gemm_rows_bf16(const void *A, int lda, int64_t n, const void *B, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
                           const void *bias, hipStream_t stream);
 int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream);
+// counting sort of positions 0..n-1 by ids[position] (mot_backward.hip); ws_ints: group_positions_ws_ints(n, rows) int32
+size_t group_positions_ws_ints(int64_t n, int64_t rows);
+int launch_group_positions(const int32_t *ids, int64_t n, int64_t rows, int32_t *ws_ints, const int32_t **pos_sorted, const int32_t **id_sorted,
+                           uint32_t *status, hipStream_t stream);
 // zero n 32-bit words with a kernel (not hipMemsetAsync: a memset node aborts on graph replay with this runtime)
 int launch_zero_words(void *p, int64_t n_words, hipStream_t stream);
 size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d);
