@@ -405,6 +405,69 @@ __global__ __launch_bounds__(kThreads) void attn_kv_rows_bwd_kernel(const AttnRo
     flush();
 }
 
+// The same sums with the head count as a template parameter: a wave then forms all HH head slices of a kv position in one
+// visit -- the rotary row of the position is read once instead of once per head, and the owner (tq, hq, c) of slot
+// (pos, hk + 1) follows from that of (pos, hk) without a division.
+template <int HH>
+__global__ __launch_bounds__(kThreads) void attn_kv_rows_bwd_h_kernel(const AttnRowsArgs A) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int HD = HH * kHd;
+    const int64_t s_begin = w * kRowsSeg, s_end = min(A.P, s_begin + kRowsSeg);
+    float dv0[HH], dv1[HH], dk0[HH], dk1[HH];
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+#pragma unroll
+        for (int hk = 0; hk < HH; ++hk) {
+            float *ok = A.dkn_tab + (int64_t)cur * HD + hk * kHd, *ov = A.dvl_tab + (int64_t)cur * HD + hk * kHd;
+            atomicAdd(ok + lane, dk0[hk]); atomicAdd(ok + 64 + lane, dk1[hk]);
+            atomicAdd(ov + lane, dv0[hk]); atomicAdd(ov + 64 + lane, dv1[hk]);
+        }
+    };
+    for (int64_t s0 = s_begin; s0 < s_end; s0 += 64) {
+        const int cnt = (int)min((int64_t)64, s_end - s0);
+        int vpos = 0, vid = 0;
+        if (lane < cnt) { vpos = A.pos_sorted[s0 + lane]; vid = A.id_sorted[s0 + lane]; }
+        for (int k = 0; k < cnt; ++k) {
+            const int64_t pos = __builtin_amdgcn_readlane(vpos, k);
+            const int id = __builtin_amdgcn_readlane(vid, k);
+            if (id != cur) {
+                flush();
+                cur = id;
+#pragma unroll
+                for (int hk = 0; hk < HH; ++hk) dv0[hk] = dv1[hk] = dk0[hk] = dk1[hk] = 0.f;
+            }
+            const float ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            // owner of slot (pos, 0); the following slots advance the key index c, then the query index qi
+            int64_t qi, tq; int c, hq;
+            if (A.layout == 0) {
+                const int64_t r = pos * HH;
+                qi = r / A.bpt; c = (int)(r - qi * A.bpt);
+                hq = (int)(qi / A.T); tq = qi - (int64_t)hq * A.T;
+            } else {
+                tq = pos / A.bpt; c = (int)(pos - tq * A.bpt); hq = 0; qi = 0;
+            }
+#pragma unroll
+            for (int hk = 0; hk < HH; ++hk) {
+                if (A.layout != 0) hq = hk;
+                const int64_t sidx = (tq * HH + hq) * A.bpt + c, row = tq * HD + hq * kHd;
+                const float p = A.pw[sidx], ds = A.dsw[sidx];
+                dv0[hk] += p * A.dy[row + lane];
+                dv1[hk] += p * A.dy[row + 64 + lane];
+                const float g0 = ds * A.qrot[row + lane], g1 = ds * A.qrot[row + 64 + lane];
+                dk0[hk] += g0 * ck - g1 * sk;
+                dk1[hk] += g0 * sk + g1 * ck;
+                if (A.layout == 0 && ++c == A.bpt) {   // next flat row belongs to the next query of the (H, T) grid
+                    c = 0;
+                    if (++tq == A.T) { tq = 0; ++hq; }
+                }
+            }
+        }
+    }
+    flush();
+}
+
 // k_n = norm_head(k_pre), v_l = lambda v_pre    (the forward's kv_finish, out of place)
 __global__ __launch_bounds__(kThreads) void kv_norm_kernel(const float *__restrict__ kpre, const float *__restrict__ vpre, int64_t rows, int H,
                                                            const float *__restrict__ lambda, float eps, float *__restrict__ kn, float *__restrict__ vl) {
@@ -582,7 +645,16 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         Rw.pos_sorted = pos_sorted; Rw.id_sorted = id_sorted; Rw.P = P; Rw.T = T; Rw.bpt = d.bpt; Rw.H = H; Rw.layout = d.head_layout;
         Rw.dkn_tab = dkn_tab; Rw.dvl_tab = dvl_tab;
         const int64_t nw = (P + kRowsSeg - 1) / kRowsSeg;
-        hipLaunchKernelGGL(attn_kv_rows_bwd_kernel, dim3((unsigned)((nw + kWaves - 1) / kWaves), (unsigned)H), dim3(kThreads), 0, stream, Rw);
+        const dim3 g1((unsigned)((nw + kWaves - 1) / kWaves));
+        switch (H) {
+            case 1: hipLaunchKernelGGL(attn_kv_rows_bwd_h_kernel<1>, g1, dim3(kThreads), 0, stream, Rw); break;
+            case 2: hipLaunchKernelGGL(attn_kv_rows_bwd_h_kernel<2>, g1, dim3(kThreads), 0, stream, Rw); break;
+            case 3: hipLaunchKernelGGL(attn_kv_rows_bwd_h_kernel<3>, g1, dim3(kThreads), 0, stream, Rw); break;
+            case 4: hipLaunchKernelGGL(attn_kv_rows_bwd_h_kernel<4>, g1, dim3(kThreads), 0, stream, Rw); break;
+            case 6: hipLaunchKernelGGL(attn_kv_rows_bwd_h_kernel<6>, g1, dim3(kThreads), 0, stream, Rw); break;
+            case 8: hipLaunchKernelGGL(attn_kv_rows_bwd_h_kernel<8>, g1, dim3(kThreads), 0, stream, Rw); break;
+            default: hipLaunchKernelGGL(attn_kv_rows_bwd_kernel, dim3(g1.x, (unsigned)H), dim3(kThreads), 0, stream, Rw);   // one head slice per wave
+        }
         if ((rc = check_launch("attn_kv_rows_bwd_kernel"))) return rc;
     }
     MotEmbedMixDesc ed;

@@ -143,6 +143,9 @@ def test_cross_attn_backward_vs_reference_autograd(mot, case):
     (768, 16, 4096, 150, "per_token", True, 9952),
     (256, 5, 300, 77, "as_viewed", False, 9953),        # no embedding norms
     (1024, 8, 512, 64, "as_viewed", True, 9954),        # production dims
+    (640, 7, 300, 53, "as_viewed", True, 9955),         # 5 heads: the per-head-slice variant of the table-row reduction
+    (640, 7, 300, 53, "per_token", True, 9956),
+    (384, 3, 300, 41, "per_token", False, 9957),        # 3 heads, bpt smaller than the head count
 ])
 def test_cross_attn_backward_vs_oracle(mot, D, bpt, Vt, T, layout, norms, seed):
     from mixture_of_tokenizers_amd.modules import Rotary
