@@ -226,6 +226,12 @@ size_t mot_embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc *fwd /* host */);
 int mot_embed_mix_bwd(const MotEmbedMixDesc *fwd /* host */, const MotEmbedMixGrads *grads /* host */,
                       mot_stream_t stream);
 
+/*
+ * CONCAT_LINEAR runs as several kernels inside one call (index kernels when the ids come from the ttb, a gather that
+ * writes the concat operand into the workspace, a dense MFMA kernel, a row-norm pass); the environment variable
+ * MOT_LIN_FUSED (any value, read per call -- and therefore by mot_embed_mix_workspace_bytes too) selects the one-launch
+ * tile kernel instead.  Same results to the parity bar; the workspace size differs, so size it with the same setting.
+ */
 size_t mot_embed_mix_desc_size(void); /* sizeof(MotEmbedMixDesc) in this build, for bindings */
 size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc /* host */);
 int mot_embed_mix_fwd(const MotEmbedMixDesc *desc /* host */, mot_stream_t stream);
