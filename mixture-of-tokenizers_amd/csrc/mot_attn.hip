@@ -109,10 +109,12 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
     // pass 1: scores, lane c keeps s_c; then the softmax over the bpt keys across lanes (one exp for all of them, line 287)
     float sc = -FLT_MAX;
     {
-        int64_t pos = pos0; int hk = hk0;
+        int64_t pos = pos0, pos_cs = -1; int hk = hk0;
+        float ck = 0.f, sk = 0.f;
         for (int c = 0; c < A.bpt; ++c) {
             const float *kp = A.kt + (int64_t)__builtin_amdgcn_readlane(rowv, c) * HD + hk * kHd;
-            const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            const float k0 = kp[lane], k1 = kp[64 + lane];
+            if (pos != pos_cs) { ck = A.cos_k[pos * 64 + lane]; sk = A.sin_k[pos * 64 + lane]; pos_cs = pos; }   // as_viewed walks H heads per position
             const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
             const float s = wave_sum(q0 * ka + q1 * kb) * inv_sqrt_hd;
             if (lane == c) sc = s;
@@ -288,10 +290,12 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     // pass 1: scores; lane c keeps s_c
     float sc = -FLT_MAX;
     {
-        int64_t pos = pos0; int hk = hk0;
+        int64_t pos = pos0, pos_cs = -1; int hk = hk0;
+        float ck = 0.f, sk = 0.f;
         for (int c = 0; c < A.bpt; ++c) {
             const float *kp = A.kn + row_at(c) * HD + hk * kHd;
-            const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            const float k0 = kp[lane], k1 = kp[64 + lane];
+            if (pos != pos_cs) { ck = A.cos_k[pos * 64 + lane]; sk = A.sin_k[pos * 64 + lane]; pos_cs = pos; }
             const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
             const float s = wave_sum(q0 * ka + q1 * kb) * inv_sqrt;
             if (lane == c) sc = s;
@@ -325,10 +329,12 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     // pass 3: dq_r += ds_c k_r;  dk_n = rope^T(ds_c q_r)
     float dq0 = 0.f, dq1 = 0.f;
     {
-        int64_t pos = pos0; int hk = hk0;
+        int64_t pos = pos0, pos_cs = -1; int hk = hk0;
+        float ck = 0.f, sk = 0.f;
         for (int c = 0; c < A.bpt; ++c) {
             const float *kp = A.kn + row_at(c) * HD + hk * kHd;
-            const float k0 = kp[lane], k1 = kp[64 + lane], ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
+            const float k0 = kp[lane], k1 = kp[64 + lane];
+            if (pos != pos_cs) { ck = A.cos_k[pos * 64 + lane]; sk = A.sin_k[pos * 64 + lane]; pos_cs = pos; }
             const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
             const float dsc = __shfl(ds, c, 64);
             dq0 += dsc * ka;
