@@ -118,7 +118,12 @@ def test_bf16_limits(mot):
     (256, 256, 3, 256, 1003, 8, 32, dict(bias=True, bytes_first=True), 9604),                       # mathblations dims
     (104, 24, 5, 384, 512, 2, 130, dict(norm_byte=True, norm_out=True, bytes_first=True), 9605),    # K = 224: ragged last K-step
 ])
-def test_bf16_concat_linear_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
+@pytest.mark.parametrize("tile_kernel", [False, True], ids=["composed", "fused_tile"])
+def test_bf16_concat_linear_vs_oracle(mot, monkeypatch, tile_kernel, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
+    if tile_kernel:   # the one-launch bf16 tile kernel instead of the default composed path, same bar
+        monkeypatch.setenv("MOT_LIN_FUSED", "1")
+    else:
+        monkeypatch.delenv("MOT_LIN_FUSED", raising=False)
     kw = dict(kw)
     use_bias = kw.pop("bias", False)
     tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=min(4.4, bpt / 2))
@@ -147,6 +152,12 @@ def test_bf16_concat_linear_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     far = np.abs(got.astype(np.float64) - want) > max(5e-4, float(np.abs(W).max()) * 2.0 ** -5)
     assert ulps(got, want)[far].max(initial=0) <= 2
     assert (got == want).mean() > 0.97
+    # the same with the byte ids given (the module seam)
+    xg = mot.embed_mix(dev(toks), b16(Et), b16(Eb), mode="concat_linear", bpt=bpt, ids_a=dev(pulled), weight=b16(W), bias=b16(bias), **kw)
+    gotg = host(xg.float())
+    farg = np.abs(gotg.astype(np.float64) - want) > max(5e-4, float(np.abs(W).max()) * 2.0 ** -5)
+    assert ulps(gotg, want)[farg].max(initial=0) <= 2
+    assert (gotg == want).mean() > 0.97
 
 
 def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
