@@ -174,6 +174,29 @@ def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
         assert abs(float(sb.grad) - ref["scales"][1]) < TOL * abs(ref["scales"]).max()
 
 
+def test_concat_backward_across_forward_slabs(mot):
+    """More rows than one slab of the composed forward (65 536): the per-row factors the forward keeps for the backward
+    (out_row_rnorm) and the saved output come from two slabs; gradients against the float64 oracle."""
+    Dt, Db, bpt, Dm, Vt, B, T, seed = 64, 16, 4, 96, 700, 1, 70001, 9251
+    rs = np.random.RandomState(seed)
+    toks = rs.randint(0, Vt, (B, T)).astype(np.int32)
+    ids = rs.randint(0, gi.BYTE_VOCAB, (B, T * bpt)).astype(np.int64)
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, Dt)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    K = Dt + bpt * Db
+    W = f32(gi.casted_linear_weight(seed + 4, Dm, K))
+    g = f32(rs.standard_normal((B, T, Dm)))
+    kw = dict(norm_tok=True, norm_byte=True, norm_out=True)
+    ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="concat_linear", bpt=bpt,
+                            weight=W.astype(np.float64), dtype=np.float64, **kw)
+    dEt, dEb, dW = (torch.nn.Parameter(dev(a)) for a in (Et, Eb, W))
+    x = mot.embed_mix(dev(toks), dEt, dEb, mode="concat_linear", bpt=bpt, ids_a=dev(ids), weight=dW, **kw)
+    (x * dev(g)).sum().backward()
+    mot.check_status()
+    assert rel(host(dEt.grad), ref["tok_table"]) < TOL
+    assert rel(host(dEb.grad), ref["byte_table"]) < TOL
+    assert rel(host(dW.grad), ref["weight"]) < TOL
+
+
 @pytest.mark.parametrize("D,Db,bpt,Vt,B,T,kw,seed", [
     (768, 48, 16, 4096, 4, 512, dict(norm_out=True), 9101),                                   # headline dims
     (768, 48, 16, 4096, 2, 300, dict(norm_tok=True, norm_byte=True, norm_out=True, scaled=True), 9102),
