@@ -489,6 +489,8 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
         return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
     char *u = (char *)d.workspace;
     if (N == 0) return MOT_OK;
+    if (bf && ((Dt & 7) || (Db & 7)))
+        return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear bf16: tok_dim/byte_dim must be multiples of 8 (got %d, %d)", Dt, Db);
     int rc;
     for (int64_t r0 = 0; r0 < N; r0 += kSlabRows) {
         const int64_t n = N - r0 < kSlabRows ? N - r0 : kSlabRows;
