@@ -232,6 +232,37 @@ def test_cross_attn_kv_table_cache(mot):
         assert not torch.equal(c, d)
 
 
+def test_cross_attn_forward_is_capturable_in_a_hip_graph(mot):
+    """The mixin forward is a fixed sequence of kernels on the given stream (seam gather, dense products, table kernels, attention):
+    capture it, change tokens, ids and a weight in place, replay, compare with an eager call."""
+    from mixture_of_tokenizers_amd.modules import Rotary
+    D, bpt, Vt, T, H = 256, 8, 500, 200, 2
+    rs = np.random.RandomState(9981)
+    toks = dev(rs.randint(0, Vt, (1, T)).astype(np.int32))
+    ids = dev(rs.randint(0, gi.BYTE_VOCAB, (1, T * bpt)).astype(np.int64))
+    Et, Eb = dev(f32(gi.normal_table(9982, Vt, D))), dev(f32(gi.normal_table(9983, gi.BYTE_VOCAB, D)))
+    q_w, kv_w, p_w = (dev(f32(a)) for a in gi.cross_weights(9984, D))
+    rq, rk = Rotary(128, T), Rotary(128, T * bpt)
+    kw = dict(q_w=q_w, kv_w=kv_w, proj_w=p_w, lambda_factor=torch.tensor(0.6, device=DEV), cos_q=rq.cos.to(DEV), sin_q=rq.sin.to(DEV),
+              cos_k=rk.cos.to(DEV), sin_k=rk.sin.to(DEV), bpt=bpt, n_heads=H)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        mot.functional.cross_attn(toks, ids, Et, Eb, **kw)          # warm-up: allocates the workspace
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph, stream=s):
+        out = mot.functional.cross_attn(toks, ids, Et, Eb, **kw)
+    toks.copy_(dev(rs.randint(0, Vt, (1, T)).astype(np.int32)))
+    ids.copy_(dev(rs.randint(0, gi.BYTE_VOCAB, (1, T * bpt)).astype(np.int64)))
+    q_w.mul_(1.25)
+    graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = mot.functional.cross_attn(toks, ids, Et, Eb, **kw)
+    assert torch.equal(out, ref)
+
+
 # ------------------------------------------------------------------------------------------------
 # mathblations: DigitMixinCrossAttention (model.py:239-253 -> 89-154) through wte / dte / digit_mixin of DigitFrontEnd,
 # against what the reference modules produced (tests/golden/digit_cross_attn.npz).  Same bars as above.
