@@ -263,6 +263,38 @@ def test_cross_attn_forward_is_capturable_in_a_hip_graph(mot):
     assert torch.equal(out, ref)
 
 
+def test_cross_attn_backward_is_capturable_in_a_hip_graph(mot):
+    """mot_cross_attn_bwd: zeroing kernels, the counting sort of the kv positions, the attention backward, the table-row sums, the
+    dense products and the embedding backward, all enqueued without a sync: capture, change the inputs in place, replay, compare."""
+    from mixture_of_tokenizers_amd.modules import Rotary
+    D, bpt, Vt, T, H = 256, 8, 500, 160, 2
+    rs = np.random.RandomState(9991)
+    toks = dev(rs.randint(0, Vt, (1, T)).astype(np.int32))
+    ids = dev(rs.randint(0, gi.BYTE_VOCAB, (1, T * bpt)).astype(np.int64))
+    Et, Eb = dev(f32(gi.normal_table(9992, Vt, D))), dev(f32(gi.normal_table(9993, gi.BYTE_VOCAB, D)))
+    q_w, kv_w, p_w = (dev(f32(a)) for a in gi.cross_weights(9994, D))
+    g = dev(f32(rs.standard_normal((1, T, D))))
+    rq, rk = Rotary(128, T), Rotary(128, T * bpt)
+    kw = dict(q_w=q_w, kv_w=kv_w, proj_w=p_w, lambda_factor=torch.tensor(0.6, device=DEV), cos_q=rq.cos.to(DEV), sin_q=rq.sin.to(DEV),
+              cos_k=rk.cos.to(DEV), sin_k=rk.sin.to(DEV), bpt=bpt, n_heads=H)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        mot.functional.cross_attn_backward(g, toks, ids, Et, Eb, **kw)          # warm-up: allocates the workspace
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        got = mot.functional.cross_attn_backward(g, toks, ids, Et, Eb, **kw)
+    toks.copy_(dev(rs.randint(0, Vt, (1, T)).astype(np.int32)))
+    ids.copy_(dev(rs.randint(0, gi.BYTE_VOCAB, (1, T * bpt)).astype(np.int64)))
+    g.copy_(dev(f32(rs.standard_normal((1, T, D)))))
+    graph.replay()
+    torch.cuda.synchronize()
+    ref = mot.functional.cross_attn_backward(g, toks, ids, Et, Eb, **kw)
+    for k in ("tok_table", "byte_table", "q_w", "kv_w", "proj_w", "lambda_factor"):
+        assert grel(host(got[k]), host(ref[k])) < 2 * GTOL, k        # two GPU results (atomic order differs)
+
+
 # ------------------------------------------------------------------------------------------------
 # mathblations: DigitMixinCrossAttention (model.py:239-253 -> 89-154) through wte / dte / digit_mixin of DigitFrontEnd,
 # against what the reference modules produced (tests/golden/digit_cross_attn.npz).  Same bars as above.
