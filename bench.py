@@ -314,10 +314,11 @@ def main():
             peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else 2500.0   # dense bf16 MFMA peak, MI355X_MICROARCH.md
             res["roofline"] = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s",
                                "frac": tf / peak, "traffic": traffic,
-                               "kernel": ("embed_mix_linear_bf16_kernel" if args.dtype != "f32" else
-                                          "embed_mix_linear_kernel" if os.environ.get("MOT_LIN_FUSED") else
-                                          ("tokens_to_bytes + pull_bytes + " if args.ids == "fused" else "") +
-                                          "gather_rows x2 + gemm_rows_bt_kernel + rows_rms_inplace (whole call)"),
+                               "kernel": (("embed_mix_linear_kernel" if args.dtype == "f32" else "embed_mix_linear_bf16_kernel")
+                                          if os.environ.get("MOT_LIN_FUSED") else
+                                          ("tokens_to_bytes + pull_bytes + " if args.ids == "fused" else "") + "concat_rows + " +
+                                          ("gemm_rows_bt_kernel" if args.dtype == "f32" else "gemm_rows_bf16_kernel") +
+                                          " + rows_rms_inplace (whole call)"),
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
         if args.backward and mode == "sum":
             from mixture_of_tokenizers_amd import data_creation as dc

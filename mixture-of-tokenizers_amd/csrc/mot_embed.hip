@@ -294,6 +294,69 @@ int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64
                                      stream);
 }
 
+// ------------------------------------------------------------------------------------------ concat operand
+// u[t] = [ rms_norm?(tok_table[tokens[t]]) | rms_norm?(byte_table[ids[t, k]]) for k < bpt ]  (or bytes first): the operand of the
+// concat + linear mixin, one wave per token, written as one contiguous row of K elements.  One id tensor; the byte rows' rms
+// factors come from a per-row table (rows_rnorm_kernel), the token row's from a wave reduction.  16-byte vectors throughout
+// (Dt, Db multiples of the vector length).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void concat_rows_kernel(const int32_t *__restrict__ tokens, const int64_t *__restrict__ ids, int64_t n,
+                                                               const T *__restrict__ tok_table, int64_t tok_rows, int Dt,
+                                                               const T *__restrict__ byte_table, int64_t byte_rows, int Db, int bpt, int norm_tok,
+                                                               const float *__restrict__ byte_rnorm, float eps, T *__restrict__ u, int K, int tok_lo,
+                                                               int byte_lo, uint32_t *status) {
+    using vec_t = typename Elem<T>::vec;
+    constexpr int VEC = Elem<T>::kVec;
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (t >= n) return;
+    int tok = tokens[t];
+    if ((uint64_t)(uint32_t)tok >= (uint64_t)tok_rows) {
+        if (status && lane == 0) atomicOr(status, kStatusTokenOor);
+        tok = 0;
+    }
+    const T *trow = tok_table + (int64_t)tok * Dt;
+    T *urow = u + t * K;
+    const int nvt = Dt / VEC;
+    float rs = 1.0f;
+    if (norm_tok) {
+        float ss = 0.f;
+        for (int j = lane; j < nvt; j += 64) {
+            const vec_t v = Elem<T>::loadv(trow + VEC * j);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) ss += v[e] * v[e];
+        }
+        rs = rms_scale(wave_sum(ss), Dt, eps);
+    }
+    for (int j = lane; j < nvt; j += 64) Elem<T>::storev_nt(urow + tok_lo + VEC * j, Elem<T>::loadv(trow + VEC * j) * rs);
+    const int vps = Db / VEC, nvb = bpt * vps;   // vectors per slot, per token
+    for (int j = lane; j < nvb; j += 64) {
+        const int slot = j / vps, within = (j - slot * vps) * VEC;
+        int64_t id = ids[t * bpt + slot];
+        if ((uint64_t)id >= (uint64_t)byte_rows) {
+            if (status) atomicOr(status, kStatusByteOor);
+            id = 0;
+        }
+        vec_t v = Elem<T>::loadv(byte_table + id * Db + within);
+        if (byte_rnorm) v *= byte_rnorm[id];
+        Elem<T>::storev_nt(urow + byte_lo + slot * Db + within, v);
+    }
+}
+
+int launch_concat_rows(const int32_t *tokens, const int64_t *ids, int64_t n, const void *tok_table, int64_t tok_rows, int Dt, const void *byte_table,
+                       int64_t byte_rows, int Db, int bpt, int norm_tok, const float *byte_rnorm, float eps, void *u, int K, int tok_lo, int byte_lo,
+                       uint32_t *status, int dtype, hipStream_t stream) {
+    if (n == 0) return MOT_OK;
+    const unsigned blocks = (unsigned)((n + kWaves - 1) / kWaves);
+    if (dtype == MOT_BF16)
+        hipLaunchKernelGGL(concat_rows_kernel<__bf16>, dim3(blocks), dim3(kThreads), 0, stream, tokens, ids, n, (const __bf16 *)tok_table, tok_rows, Dt,
+                           (const __bf16 *)byte_table, byte_rows, Db, bpt, norm_tok, byte_rnorm, eps, (__bf16 *)u, K, tok_lo, byte_lo, status);
+    else
+        hipLaunchKernelGGL(concat_rows_kernel<float>, dim3(blocks), dim3(kThreads), 0, stream, tokens, ids, n, (const float *)tok_table, tok_rows, Dt,
+                           (const float *)byte_table, byte_rows, Db, bpt, norm_tok, byte_rnorm, eps, (float *)u, K, tok_lo, byte_lo, status);
+    return check_launch("concat_rows_kernel");
+}
+
 int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float *out, int dtype, hipStream_t stream) {
     const int64_t rb = (rows + kWaves - 1) / kWaves;
     if (dtype == MOT_BF16)

@@ -29,6 +29,10 @@ int launch_gather_rows_placed(const void *ids_a, const void *ids_b, int ids_elem
                               int dim, int rms_norm, float eps, const float *scale, void *out, int group, int64_t out_ld,
                               uint32_t *status, uint32_t oor_flag, int dtype, hipStream_t stream);
 int launch_rows_rnorm(const void *table, int64_t rows, int dim, float eps, float *out, int dtype, hipStream_t stream);
+// the concat operand [n, K] of the concat + linear mixin in one kernel (one id tensor, Dt and Db multiples of the 16-byte vector)
+int launch_concat_rows(const int32_t *tokens, const int64_t *ids, int64_t n, const void *tok_table, int64_t tok_rows, int Dt, const void *byte_table,
+                       int64_t byte_rows, int Db, int bpt, int norm_tok, const float *byte_rnorm, float eps, void *u, int K, int tok_lo, int byte_lo,
+                       uint32_t *status, int dtype, hipStream_t stream);
 size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d);
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream);         // SUM / MEAN / NOOP
 int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream);  // CONCAT_LINEAR

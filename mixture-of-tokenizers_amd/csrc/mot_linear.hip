@@ -373,6 +373,7 @@ static size_t composed_floats(const MotEmbedMixDesc &d) {
     const size_t elems = (size_t)(n < kSlabRows ? n : kSlabRows) * (size_t)(d.tok_dim + d.bpt * d.byte_dim);
     return ((d.dtype == MOT_BF16 ? (elems + 1) / 2 : elems) + 3) & ~(size_t)3;
 }
+static size_t composed_rnorm_floats(const MotEmbedMixDesc &d) { return ((size_t)d.byte_rows + 3) & ~(size_t)3; }   // rms factors of the byte-table rows
 // ids pulled from the token->byte table: the two index kernels of the loader path run first, into the caller's out_ids_*
 // buffers when it asked for them, else into scratch behind u (2 x tokens x bpt int64)
 static size_t composed_id_words(const MotEmbedMixDesc &d) {
@@ -447,10 +448,10 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream);
 
 static int launch_composed_from_ttb(const MotEmbedMixDesc &d, hipStream_t stream) {
     const int64_t N = d.n_rows * d.tokens_per_row, slots = N * d.bpt;
-    const size_t need = composed_floats(d) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
+    const size_t need = (composed_floats(d) + composed_rnorm_floats(d)) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
     if (!d.workspace || d.workspace_bytes < need)
         return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
-    int64_t *ws_ids = (int64_t *)((float *)d.workspace + composed_floats(d));
+    int64_t *ws_ids = (int64_t *)((float *)d.workspace + composed_floats(d) + composed_rnorm_floats(d));
     int64_t *padded = d.out_ids_padded ? d.out_ids_padded : ws_ids;
     int64_t *pulled = d.out_ids_pulled ? d.out_ids_pulled : ws_ids + slots;
     int rc;
@@ -484,20 +485,31 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
     const bool bf = d.dtype == MOT_BF16;
     const size_t esz = bf ? 2 : 4;
     const float eps = d.eps > 0.f ? d.eps : (bf ? kBf16Eps : FLT_EPSILON);
-    const size_t need = composed_floats(d) * sizeof(float);
+    const size_t need = (composed_floats(d) + composed_rnorm_floats(d)) * sizeof(float);
     if (!d.workspace || d.workspace_bytes < need)
         return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
     char *u = (char *)d.workspace;
+    float *rn = (float *)d.workspace + composed_floats(d);
     if (N == 0) return MOT_OK;
     if (bf && ((Dt & 7) || (Db & 7)))
         return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear bf16: tok_dim/byte_dim must be multiples of 8 (got %d, %d)", Dt, Db);
     int rc;
+    // one id tensor and 16-byte-vector rows: the concat operand comes from ONE kernel (concat_rows_kernel, byte-row rms factors from a
+    // table built once per call); otherwise from the two seam gathers
+    const int vec = bf ? 8 : 4;
+    const bool one_kernel = !d.ids_b && (Dt % vec) == 0 && (Db % vec) == 0;
+    if (one_kernel && d.norm_byte && (rc = launch_rows_rnorm(d.byte_table, d.byte_rows, Db, eps, rn, d.dtype, stream))) return rc;
     for (int64_t r0 = 0; r0 < N; r0 += kSlabRows) {
         const int64_t n = N - r0 < kSlabRows ? N - r0 : kSlabRows;
-        if ((rc = launch_gather_rows_placed(d.tokens + r0, nullptr, 4, n, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, nullptr, u + tok_lo * esz, 1, K,
-                                            d.status, kStatusTokenOor, d.dtype, stream))) return rc;
-        if ((rc = launch_gather_rows_placed(d.ids_a + r0 * bpt, d.ids_b ? d.ids_b + r0 * bpt : nullptr, 8, n * bpt, d.byte_table, d.byte_rows, Db,
-                                            d.norm_byte, eps, nullptr, u + byte_lo * esz, bpt, K, d.status, kStatusByteOor, d.dtype, stream))) return rc;
+        if (one_kernel) {
+            if ((rc = launch_concat_rows(d.tokens + r0, d.ids_a + r0 * bpt, n, d.tok_table, d.tok_rows, Dt, d.byte_table, d.byte_rows, Db, bpt, d.norm_tok,
+                                         d.norm_byte ? rn : nullptr, eps, u, K, tok_lo, byte_lo, d.status, d.dtype, stream))) return rc;
+        } else {
+            if ((rc = launch_gather_rows_placed(d.tokens + r0, nullptr, 4, n, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, nullptr, u + tok_lo * esz, 1, K,
+                                                d.status, kStatusTokenOor, d.dtype, stream))) return rc;
+            if ((rc = launch_gather_rows_placed(d.ids_a + r0 * bpt, d.ids_b ? d.ids_b + r0 * bpt : nullptr, 8, n * bpt, d.byte_table, d.byte_rows, Db,
+                                                d.norm_byte, eps, nullptr, u + byte_lo * esz, bpt, K, d.status, kStatusByteOor, d.dtype, stream))) return rc;
+        }
         char *out = (char *)d.out + r0 * Dm * esz;
         float *rr = d.out_row_rnorm ? d.out_row_rnorm + r0 : nullptr;
         const unsigned nb = (unsigned)((n + kWaves - 1) / kWaves);
@@ -514,7 +526,7 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
 }
 
 size_t embed_mix_linear_composed_workspace_bytes(const MotEmbedMixDesc &d) {
-    return composed_floats(d) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
+    return (composed_floats(d) + composed_rnorm_floats(d)) * sizeof(float) + composed_id_words(d) * sizeof(int64_t);
 }
 int launch_embed_mix_linear_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
     return d.id_source == MOT_IDS_FROM_TTB ? launch_composed_from_ttb(d, stream) : launch_composed(d, stream);
