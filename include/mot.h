@@ -9,8 +9,11 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless a comment says "host"
- *   - the caller owns all buffers (inputs, outputs, workspace); the library allocates nothing
- *     and keeps no state between calls, so calls are re-entrant and hipGraph-capturable
+ *   - the caller owns all buffers (inputs, outputs, workspace); the library allocates nothing and
+ *     reads no environment variable; every choice between kernels is a field of the descriptor
+ *     (MotEmbedMixDesc.flags).  The only thing it remembers between calls is, per device, which
+ *     kernels already had their dynamic-LDS limit raised (hipFuncSetAttribute, idempotent), so
+ *     calls are re-entrant and hipGraph-capturable
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the
  *     default stream) and never synchronises the host
  *   - return value: MOT_OK or a negative MotStatus; mot_last_error() gives a thread-local
@@ -27,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 8
+#define MOT_ABI_VERSION 9
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -140,9 +143,17 @@ int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, in
  *       idsA = pulled (or padded when pull_dir == NONE); idsB = padded iff add_padded
  *   MOT_IDS_GIVEN:    idsA = ids_a, idsB = ids_b (NULL = none)
  */
+/* MotEmbedMixDesc.flags: kernel selection, resolved by the caller once (the Python shim reads its own switches at
+ * import); results agree to the parity bar either way, the workspace size may differ -- size it with the same flags. */
+#define MOT_FLAG_LINEAR_ONE_LAUNCH 1u /* CONCAT_LINEAR: the one-launch tile kernel instead of the composed kernels       */
+#define MOT_FLAG_MEAN_GENERIC 2u      /* MEAN: the whole-row kernel even where the LDS column-slice kernel qualifies     */
+#define MOT_FLAG_BWD_DU_FP32 4u       /* CONCAT_LINEAR backward, bf16: du = dy.W on the fp32 MFMA instead of the bf16 one */
+
 typedef struct MotEmbedMixDesc {
     uint32_t struct_size; /* sizeof(MotEmbedMixDesc), checked */
     int32_t dtype;        /* MotDType of tables / weight / out */
+    uint32_t flags;       /* MOT_FLAG_* */
+    uint32_t reserved0;   /* must be 0 */
 
     /* problem */
     int64_t n_rows;         /* B */
@@ -228,9 +239,9 @@ int mot_embed_mix_bwd(const MotEmbedMixDesc *fwd /* host */, const MotEmbedMixGr
 
 /*
  * CONCAT_LINEAR runs as several kernels inside one call (index kernels when the ids come from the ttb, a gather that
- * writes the concat operand into the workspace, a dense MFMA kernel, a row-norm pass); the environment variable
- * MOT_LIN_FUSED (any value, read per call -- and therefore by mot_embed_mix_workspace_bytes too) selects the one-launch
- * tile kernel instead.  Same results to the parity bar; the workspace size differs, so size it with the same setting.
+ * writes the concat operand into the workspace, a dense MFMA kernel, a row-norm pass); MOT_FLAG_LINEAR_ONE_LAUNCH in
+ * desc->flags selects the one-launch tile kernel instead.  Same results to the parity bar; the workspace size differs,
+ * so mot_embed_mix_workspace_bytes must see the same flags as the call.
  */
 size_t mot_embed_mix_desc_size(void); /* sizeof(MotEmbedMixDesc) in this build, for bindings */
 size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc /* host */);

@@ -23,7 +23,8 @@ MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32, BF16 = 0, 1
 MAX_BPT = 64
-ABI_VERSION = 8
+ABI_VERSION = 9
+FLAG_LINEAR_ONE_LAUNCH, FLAG_MEAN_GENERIC, FLAG_BWD_DU_FP32 = 1, 2, 4
 HEADS_AS_VIEWED, HEADS_PER_TOKEN = 0, 1
 
 
@@ -46,7 +47,7 @@ EXPORTS = (
 class MotEmbedMixDesc(C.Structure):
     """Field-for-field mirror of struct MotEmbedMixDesc (include/mot.h)."""
     _fields_ = [
-        ("struct_size", C.c_uint32), ("dtype", C.c_int32),
+        ("struct_size", C.c_uint32), ("dtype", C.c_int32), ("flags", C.c_uint32), ("reserved0", C.c_uint32),
         ("n_rows", C.c_int64), ("tokens_per_row", C.c_int64), ("bpt", C.c_int32), ("mode", C.c_int32),
         ("tokens", C.c_void_p), ("id_source", C.c_int32), ("pull_dir", C.c_int32),
         ("ttb", C.c_void_p), ("ttb_rows", C.c_int64), ("ttb_elem_bytes", C.c_int32), ("add_padded", C.c_int32),

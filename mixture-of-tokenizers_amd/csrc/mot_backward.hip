@@ -867,12 +867,8 @@ __global__ __launch_bounds__(1024) void bwd_scan_kernel(const int32_t *__restric
 
 template <int MODE, int NE>
 static int launch_bwd(const BwdArgs &A, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_bwd_kernel<MODE, NE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_bwd_kernel): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};   // per-device bits
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_kernel<MODE, NE>, lds_ok, "embed_mix_bwd_kernel")) return rc_lds;
     int64_t blocks = ((A.n_tokens + kWindow - 1) / kWindow + kBwdWaves - 1) / kBwdWaves;
     if (blocks > 256) blocks = 256;  // one persistent workgroup per CU
     hipLaunchKernelGGL((embed_mix_bwd_kernel<MODE, NE>), dim3((unsigned)blocks), dim3(kBwdThreads), lds, stream, A);
@@ -881,12 +877,8 @@ static int launch_bwd(const BwdArgs &A, size_t lds, hipStream_t stream) {
 
 template <int MODE, int NE, bool BF>
 static int launch_bwd_full_t(const BwdArgs &A, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_bwd_full_kernel<MODE, NE, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_bwd_full_kernel): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};   // per-device bits
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_full_kernel<MODE, NE, BF>, lds_ok, "embed_mix_bwd_full_kernel")) return rc_lds;
     int64_t blocks = (A.n_tokens + 16 * kBwdWaves - 1) / (16 * kBwdWaves);   // >= 16 sorted positions per wave
     if (blocks > 256) blocks = 256;   // one workgroup per CU
     hipLaunchKernelGGL((embed_mix_bwd_full_kernel<MODE, NE, BF>), dim3((unsigned)blocks), dim3(kBwdThreads), lds, stream, A);
@@ -1441,7 +1433,7 @@ static Du16Layout du16_layout(const MotEmbedMixDesc &d) {
 static bool du16_usable(const MotEmbedMixDesc &d) {
     const int K = d.tok_dim + d.bpt * d.byte_dim;
     return d.dtype == MOT_BF16 && (d.model_dim & 7) == 0 && (K & 7) == 0 && K <= 1024 && ((d.n_rows * d.tokens_per_row) & 7) == 0 &&
-           !getenv("MOT_NO_DU16");
+           !(d.flags & MOT_FLAG_BWD_DU_FP32);
 }
 
 __global__ __launch_bounds__(kThreads) void narrow_kernel(const float *__restrict__ src, int64_t n, __bf16 *__restrict__ dst) {

@@ -24,6 +24,18 @@ int check_launch(const char *what) {
     return MOT_OK;
 }
 
+int ensure_max_dyn_lds(const void *kernel, std::atomic<uint64_t> &done, const char *name) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(MOT_EHIP, "hipGetDevice: %s", hipGetErrorString(e));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (dev < 64 && (done.load(std::memory_order_acquire) & bit)) return MOT_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(%s): %s", name, hipGetErrorString(e));
+    if (dev < 64) done.fetch_or(bit, std::memory_order_release);
+    return MOT_OK;
+}
+
 static int check_bpt(const char *fn, int bpt) {
     if (bpt < 1 || bpt > MOT_MAX_BPT) return set_error(MOT_EUNSUPPORTED, "%s: bytes_per_token %d outside [1, %d]", fn, bpt, MOT_MAX_BPT);
     return MOT_OK;
@@ -34,6 +46,8 @@ static int validate_embed_mix(const MotEmbedMixDesc *d) {
     if (d->struct_size != sizeof(MotEmbedMixDesc))
         return set_error(MOT_EINVAL, "embed_mix: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(MotEmbedMixDesc));
     if (d->dtype != MOT_F32 && d->dtype != MOT_BF16) return set_error(MOT_EINVAL, "embed_mix: bad dtype %d", d->dtype);
+    if ((d->flags & ~(MOT_FLAG_LINEAR_ONE_LAUNCH | MOT_FLAG_MEAN_GENERIC | MOT_FLAG_BWD_DU_FP32)) || d->reserved0)
+        return set_error(MOT_EINVAL, "embed_mix: unknown flags 0x%x / reserved0 %u", d->flags, d->reserved0);
     if (d->n_rows < 0 || d->tokens_per_row < 0) return set_error(MOT_ESHAPE, "embed_mix: negative shape");
     if (d->mode < MOT_MIX_NOOP || d->mode > MOT_MIX_CONCAT_LINEAR) return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d->mode);
     if (!d->tokens || !d->tok_table || !d->out) return set_error(MOT_EINVAL, "embed_mix: tokens/tok_table/out must be non-null");

@@ -11,8 +11,6 @@
 //            rms-norm reductions are wave shuffles, the mixed row is written once with
 //            non-temporal 16 B stores.  Algorithmic traffic: 4 + 2*bpt + 4*Dt B read and
 //            4*Dm B written per token; HBM-bound.
-#include <stdlib.h>
-
 #include "mot_mix.hpp"
 
 namespace mot {
@@ -501,12 +499,8 @@ static int launch_mean_lds(MixArgs A, const MotEmbedMixDesc &d, int slice_cols, 
     parts = (N + per - 1) / per;
     A.T = N;                                                  // flat token addressing (rows are independent without a pull)
     const size_t lds = (size_t)d.byte_rows * slice_cols * sizeof(T);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mean_lds_kernel<T, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mean_lds_kernel): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};   // per-device bits
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, 4>, lds_ok, "embed_mean_lds_kernel")) return rc_lds;
     hipLaunchKernelGGL((embed_mean_lds_kernel<T, 4>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
     return check_launch("embed_mean_lds_kernel");
 }
@@ -514,7 +508,7 @@ static int launch_mean_lds(MixArgs A, const MotEmbedMixDesc &d, int slice_cols, 
 // slice width (columns) for the LDS-table MEAN kernel, or 0 when the shape does not qualify
 static int mean_lds_slice(const MotEmbedMixDesc &d) {
     if (d.mode != MOT_MIX_MEAN || d.id_source != MOT_IDS_GIVEN || d.ids_b || d.norm_tok || d.norm_out || d.counters || d.out_ids_padded ||
-        d.out_ids_pulled || getenv("MOT_NO_MEAN_LDS"))
+        d.out_ids_pulled || (d.flags & MOT_FLAG_MEAN_GENERIC))
         return 0;
     const int esize = d.dtype == MOT_BF16 ? 2 : 4, chunk = 64 * (16 / esize);   // columns one wave covers with 16-byte lanes
     if (d.tok_dim % chunk || d.n_rows * d.tokens_per_row < 16384) return 0;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/mot.h"
 
 namespace mot {
@@ -11,6 +13,10 @@ namespace mot {
 int set_error(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 // hipGetLastError() after a launch -> MOT_OK / MOT_EHIP (with the kernel name in the message).
 int check_launch(const char *what);
+
+// Raises a kernel's dynamic-LDS limit to 160 KiB once per (kernel, device): `done` is that kernel's per-device bit set
+// (a function-local static std::atomic at the call site).  hipFuncSetAttribute is idempotent, so a race costs a second call.
+int ensure_max_dyn_lds(const void *kernel, std::atomic<uint64_t> &done, const char *name);
 
 int pick_tile_tokens(int64_t n_rows, int64_t tokens_per_row, int bpt, bool with_ids);
 

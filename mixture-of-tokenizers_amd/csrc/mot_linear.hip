@@ -363,7 +363,7 @@ static int nt_of(int Dm) {
 // scratch stays bounded.  The fused kernel remains the path for ids pulled in-kernel from the token->byte table.
 constexpr int64_t kSlabRows = 65536;
 bool embed_mix_linear_is_composed(const MotEmbedMixDesc &d) {
-    if (getenv("MOT_LIN_FUSED")) return false;   // A-B / test switch: the fused tile kernels for everything (read per call)
+    if (d.flags & MOT_FLAG_LINEAR_ONE_LAUNCH) return false;   // A-B / test switch: the one-launch tile kernels for everything
     return d.bpt > 0 && !d.scale_tok && !d.scale_byte;
 }
 static bool composed_path(const MotEmbedMixDesc &d) { return embed_mix_linear_is_composed(d); }
@@ -552,12 +552,8 @@ static int launch_lin(LinArgs &P, const MotEmbedMixDesc &d, hipStream_t stream) 
     const size_t lds = lin_lds_bytes(P.DmPad, P.M.bpt, BK, TM);
     if (lds > 160 * 1024)
         return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear: needs %zu B of LDS (model_dim %d, bpt %d) > 160 KiB", lds, P.Dm, P.M.bpt);
-    static bool attr_set = false;  // raising the dynamic-LDS limit is idempotent; a race sets it twice at worst
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_kernel<MT, NT, BK, OCC, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_linear_kernel): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};   // per-device bits
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_linear_kernel<MT, NT, BK, OCC, ABL>, lds_ok, "embed_mix_linear_kernel")) return rc_lds;
     hipLaunchKernelGGL((embed_mix_linear_kernel<MT, NT, BK, OCC, ABL>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, P);
     return check_launch("embed_mix_linear_kernel");
 }

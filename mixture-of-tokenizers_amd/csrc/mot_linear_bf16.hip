@@ -346,12 +346,8 @@ static int launch_lin16(LinArgs16 &P, const MotEmbedMixDesc &d, hipStream_t stre
     const size_t lds = lin16_lds_bytes(NT * 128, P.M.bpt, TM);
     if (lds > 160 * 1024)
         return set_error(MOT_EUNSUPPORTED, "embed_mix concat_linear bf16: needs %zu B of LDS (model_dim %d, bpt %d) > 160 KiB", lds, P.Dm, P.M.bpt);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)embed_mix_linear_bf16_kernel<MT, NT, RG>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return set_error(MOT_EHIP, "hipFuncSetAttribute(embed_mix_linear_bf16_kernel): %s", hipGetErrorString(e));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};   // per-device bits
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_linear_bf16_kernel<MT, NT, RG>, lds_ok, "embed_mix_linear_bf16_kernel")) return rc_lds;
     hipLaunchKernelGGL((embed_mix_linear_bf16_kernel<MT, NT, RG>), dim3((unsigned)blocks), dim3(kThreads * RG), lds, stream, P);
     return check_launch("embed_mix_linear_bf16_kernel");
 }

@@ -62,19 +62,19 @@ def make_embedding(filename: str, vocab_size: int) -> nn.Embedding:
     return emb
 
 
-_plain_cache: dict[int, tuple] = {}
-
-
 def _table_of(emb) -> torch.Tensor:
     if isinstance(emb, TokenToBytesTable):
         return emb.int_table()
     if isinstance(emb, nn.Embedding):  # e.g. built by the reference's own make_embedding
+        # the integer copy lives ON the module (it dies with it; a dict keyed by id(emb) could serve a later module
+        # that reuses the id), and is rebuilt when the weight storage, version, device or dtype changes.  Writes
+        # through ``weight.data[...] = `` do not bump the version: call ``del emb._mot_int_cache`` after those.
         w = emb.weight
         key = (w.data_ptr(), w._version, w.device, w.dtype)
-        hit = _plain_cache.get(id(emb))
+        hit = emb.__dict__.get("_mot_int_cache")
         if hit is None or hit[0] != key:
             hit = (key, int_table_of(w))
-            _plain_cache[id(emb)] = hit
+            emb.__dict__["_mot_int_cache"] = hit
         return hit[1]
     if isinstance(emb, torch.Tensor):
         return emb if emb.dtype in (torch.int16, torch.int32) else int_table_of(emb)

@@ -8,11 +8,27 @@ them as opaque calls.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import torch
 
 from . import _capi as capi
+
+# Kernel-selection switches, read ONCE at import (the C library itself reads no environment variable; the choice travels
+# in MotEmbedMixDesc.flags).  Every call can override them with one_launch= / mean_generic= / du_fp32=.
+_ENV_FLAGS = ((capi.FLAG_LINEAR_ONE_LAUNCH if os.environ.get("MOT_LIN_FUSED") else 0)
+              | (capi.FLAG_MEAN_GENERIC if os.environ.get("MOT_NO_MEAN_LDS") else 0)
+              | (capi.FLAG_BWD_DU_FP32 if os.environ.get("MOT_NO_DU16") else 0))
+
+
+def _flags(one_launch=None, mean_generic=None, du_fp32=None) -> int:
+    f = _ENV_FLAGS
+    for bit, v in ((capi.FLAG_LINEAR_ONE_LAUNCH, one_launch), (capi.FLAG_MEAN_GENERIC, mean_generic), (capi.FLAG_BWD_DU_FP32, du_fp32)):
+        if v is not None:
+            f = (f | bit) if v else (f & ~bit)
+    return f
+
 
 _MODES = {"noop": capi.MIX_NOOP, "sum": capi.MIX_SUM, "mean": capi.MIX_MEAN, "concat_linear": capi.MIX_CONCAT_LINEAR}
 _PULLS = {None: capi.PULL_NONE, "none": capi.PULL_NONE, "left": capi.PULL_LEFT, "right": capi.PULL_RIGHT}
@@ -121,18 +137,33 @@ class MixResult:
 
 
 _workspaces: dict[tuple[int, int], torch.Tensor] = {}
+_retired: dict[tuple[int, int], list[torch.Tensor]] = {}
 
 
 def _workspace(dev: torch.device, nbytes: int) -> torch.Tensor | None:
-    """Per-(device, stream) scratch reused across calls (kernels on one stream are ordered)."""
+    """Per-(device, stream) scratch reused across calls (kernels on one stream are ordered).
+
+    A captured hipGraph bakes the raw workspace pointer into its kernel nodes, so a buffer that a larger request
+    replaces is NOT handed back to the allocator: it moves to a retired list and stays valid for whatever graph
+    still points at it (workspaces only ever grow, geometrically, so the list holds a handful of buffers whose
+    sizes sum to less than the live one).  `release_workspaces()` drops everything once no graph needs them."""
     if nbytes == 0:
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), capi.stream_of(dev))
     w = _workspaces.get(key)
     if w is None or w.numel() < nbytes:
+        if w is not None:
+            _retired.setdefault(key, []).append(w)
+            nbytes = max(nbytes, 2 * w.numel())
         w = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
         _workspaces[key] = w
     return w
+
+
+def release_workspaces() -> None:
+    """Frees every library workspace (live and retired).  Call only when no captured graph that used them will be replayed."""
+    _workspaces.clear()
+    _retired.clear()
 
 
 @torch.compiler.disable
@@ -146,12 +177,15 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
               scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
               out: torch.Tensor | None = None, return_ids: bool = False,
               counters: torch.Tensor | None = None, row_rnorm: torch.Tensor | None = None,
+              one_launch: bool | None = None, mean_generic: bool | None = None,
               _plan: bool = False) -> torch.Tensor | MixResult:
     """One fused launch of mot_embed_mix_fwd; see include/mot.h for the per-token formula.
 
     tokens (B, T) integer.  Byte ids either come from `ttb` (+ `pull` = "left" | "right" | None,
     + `add_padded`) inside the kernel, or are given as `ids_a` / `ids_b` (B, T*bpt) int64.
     `scale_*` are 0-dim/1-element DEVICE tensors (learned scalars are read on the device).
+    `one_launch` (concat_linear: the one-launch tile kernel instead of the composed kernels) and `mean_generic` (mean: the
+    whole-row kernel instead of the LDS column-slice kernel) override the import-time defaults (MotEmbedMixDesc.flags).
     """
     m = _MODES[mode]
     if tokens.ndim == 1:
@@ -170,6 +204,7 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     d = capi.MotEmbedMixDesc()
     d.struct_size = C.sizeof(capi.MotEmbedMixDesc)
     d.dtype = capi.dtype_code(fdt)
+    d.flags = _flags(one_launch, mean_generic)
     d.n_rows, d.tokens_per_row, d.bpt, d.mode = B, T, int(bpt), m
     d.tokens = capi.ptr(tok)
     d.tok_table, d.tok_rows, d.tok_dim = capi.ptr(tt), tt.shape[0], tt.shape[1]
@@ -311,16 +346,30 @@ class _EmbedMixFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gx, *_):
         tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b, weight, bias, x, rn = ctx.saved_tensors
+        # Parameters whose .grad is managed by grad_sync.GradBucket take the kernel's += directly (mot_embed_mix_bwd only ever
+        # adds into its outputs): no temporary table-sized gradient, no zero fill, no AccumulateGrad pass over it.  Everything
+        # else gets a fresh fp32 gradient handed to autograd as usual.
+        direct = {k: p.grad for k, p in (("tok_table", tok_table), ("byte_table", byte_table), ("weight", weight), ("bias", bias))
+                  if _accumulates_in_place(p)}
         g = embed_mix_backward(gx, tokens, tok_table.detach(), None if byte_table is None else byte_table.detach(),
                                ids_a=ids_a, ids_b=ids_b,
                                scale_tok=None if scale_tok is None else scale_tok.detach(),
                                scale_byte=None if scale_byte is None else scale_byte.detach(),
                                weight=None if weight is None else weight.detach(), bias=None if bias is None else bias.detach(),
-                               out=None if x is None else x.detach(), row_rnorm=rn, **ctx.kw)
-        def like(t, p):  # bf16 parameters get their gradient rounded once, from the fp32 sums
-            return None if t is None or p is None else t.to(p.dtype).reshape(p.shape)
-        return (like(g["tok_table"], tok_table), like(g.get("byte_table"), byte_table), like(g.get("scale_tok"), scale_tok),
-                like(g.get("scale_byte"), scale_byte), like(g.get("weight"), weight), like(g.get("bias"), bias), None, None)
+                               out=None if x is None else x.detach(), row_rnorm=rn, into=direct, **ctx.kw)
+        def like(k, p):  # bf16 parameters get their gradient rounded once, from the fp32 sums
+            t = g.get(k)
+            return None if t is None or p is None or k in direct else t.to(p.dtype).reshape(p.shape)
+        return (like("tok_table", tok_table), like("byte_table", byte_table), like("scale_tok", scale_tok),
+                like("scale_byte", scale_byte), like("weight", weight), like("bias", bias), None, None)
+
+
+def _accumulates_in_place(p) -> bool:
+    """True for a leaf parameter that grad_sync.GradBucket has bound to its flat buffer: fp32, contiguous .grad present."""
+    if p is None or not getattr(p, "_mot_grad_in_place", False) or not p.requires_grad or not p.is_leaf:
+        return False
+    gr = p.grad
+    return gr is not None and gr.dtype == torch.float32 and gr.is_contiguous() and gr.shape == p.shape and gr.device == p.device
 
 
 @torch.compiler.disable
@@ -330,7 +379,7 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
                        scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
                        weight: torch.Tensor | None = None, bias: torch.Tensor | None = None, bytes_first: bool = False,
                        out: torch.Tensor | None = None, row_rnorm: torch.Tensor | None = None,
-                       into: dict | None = None) -> dict:
+                       into: dict | None = None, du_fp32: bool | None = None, one_launch: bool | None = None) -> dict:
     """One launch of mot_embed_mix_bwd.  Returns dense fp32 gradients {tok_table, byte_table, scale_tok,
     scale_byte, weight, bias} -- fp32 also when the tables are bfloat16 (accumulated in fp32; the autograd
     node rounds once to the parameter dtype); pass `into` (same keys, fp32) to accumulate into existing
@@ -349,6 +398,7 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
     d = capi.MotEmbedMixDesc()
     d.struct_size = C.sizeof(capi.MotEmbedMixDesc)
     d.dtype = code
+    d.flags = _flags(one_launch=one_launch, du_fp32=du_fp32)
     d.n_rows, d.tokens_per_row, d.bpt, d.mode = B, T, int(bpt), m
     d.tokens = capi.ptr(tok)
     d.tok_table, d.tok_rows, d.tok_dim, d.model_dim = capi.ptr(tt), tt.shape[0], tt.shape[1], tt.shape[1]

@@ -36,6 +36,9 @@ class GradBucket:
         self.group = process_group
         for p, off in zip(self.params, offs):
             p.grad = self.flat[off:off + p.numel()].view_as(p)
+            # fp32 views: the fused backward adds into them directly (functional._EmbedMixFn.backward) instead of
+            # materialising a table-sized temporary for autograd's AccumulateGrad to add
+            p._mot_grad_in_place = dt == torch.float32
 
     def zero_(self) -> None:
         """Replaces optimizer.zero_grad(set_to_none=True) for these parameters (keeps the views)."""

@@ -18,10 +18,11 @@ mixes and writes x.  Anything that needs the tensors themselves calls ``handle.m
 Parameters are read from their live storage at launch time, so weight tying
 (``wte.weight = lm_head.weight``, model.py:316-317) and in-place optimizer updates are honoured.
 
-Autograd: the fused paths (sum, tokens-only/noop, concat + linear) are differentiable with fp32
-parameters: one backward call produces the dense table / weight / bias / scalar gradients.  What is
-not built raises instead of silently dropping the graph: bf16 parameters, the materialised
-(non-fused) seam tensors, and norm(emb(padded) + emb(pulled)) (add_padded_and_pulled).
+Autograd: the fused paths (sum, tokens-only/noop, concat + linear incl. norm(emb(padded) + emb(pulled)),
+and the cross-attention mixin over one id tensor) are differentiable with fp32 or bf16 parameters: one
+backward call produces dense fp32 gradient sums for the tables / weight / bias / scalars, rounded once to
+the parameter dtype.  What has no backward raises instead of silently dropping the graph: the MEAN mix,
+the materialised (non-fused) seam tensors, and the cross-attention mixin over two id tensors.
 """
 from __future__ import annotations
 
@@ -104,10 +105,11 @@ class CastedLinear(nn.Linear):  # train_gpt.py:175-186
 # the handle that crosses the embed / mixin seam
 # ------------------------------------------------------------------------------------------------
 def _check_forward_only(*params) -> None:
+    """The materialised seam tensors (fused=False) come from a plain gather launch that records no autograd node."""
     if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
         raise RuntimeError(
-            "mixture-of-tokenizers_amd implements the forward of the embedding front-end only (backward is the "
-            "next scope row); call it under torch.no_grad() or with frozen parameters")
+            "mixture-of-tokenizers_amd: the materialised (non-fused) seam tensors have no backward -- gradients flow through "
+            "the fused path (FlexibleEmbedding(fused=True) + ByteMixin); call this under torch.no_grad() or with frozen parameters")
 
 
 def _f32(p: Tensor, what: str) -> Tensor:

@@ -119,12 +119,8 @@ def test_bf16_limits(mot):
     (104, 24, 5, 384, 512, 2, 130, dict(norm_byte=True, norm_out=True, bytes_first=True), 9605),    # K = 224: ragged last K-step
 ])
 @pytest.mark.parametrize("tile_kernel", [False, True], ids=["composed", "fused_tile"])
-def test_bf16_concat_linear_vs_oracle(mot, monkeypatch, tile_kernel, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
-    if tile_kernel:   # the one-launch bf16 tile kernel instead of the default composed path, same bar
-        monkeypatch.setenv("MOT_LIN_FUSED", "1")
-    else:
-        monkeypatch.delenv("MOT_LIN_FUSED", raising=False)
-    kw = dict(kw)
+def test_bf16_concat_linear_vs_oracle(mot, tile_kernel, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
+    kw = dict(kw)   # tile_kernel: the one-launch bf16 tile kernel instead of the default composed path, same bar
     use_bias = kw.pop("bias", False)
     tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=min(4.4, bpt / 2))
     toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
@@ -141,7 +137,7 @@ def test_bf16_concat_linear_vs_oracle(mot, monkeypatch, tile_kernel, Dt, Db, bpt
         orc.set_eps(0.0); orc.set_round_segments_bf16(False)
     b16 = lambda a: None if a is None else dev(a).bfloat16()
     x = mot.embed_mix(dev(toks), b16(Et), b16(Eb), mode="concat_linear", bpt=bpt, ttb=dev(tab), pull="left", weight=b16(W),
-                      bias=b16(bias), **kw)
+                      bias=b16(bias), one_launch=tile_kernel, **kw)
     assert x.dtype == torch.bfloat16 and x.shape == (B, T, Dm)
     got, want = host(x.float()), orc.bf16_round(ref)
     # The concat operand is rounded to bf16 before the contraction (as in the reference); where raw*r lands on a
@@ -153,7 +149,8 @@ def test_bf16_concat_linear_vs_oracle(mot, monkeypatch, tile_kernel, Dt, Db, bpt
     assert ulps(got, want)[far].max(initial=0) <= 2
     assert (got == want).mean() > 0.97
     # the same with the byte ids given (the module seam)
-    xg = mot.embed_mix(dev(toks), b16(Et), b16(Eb), mode="concat_linear", bpt=bpt, ids_a=dev(pulled), weight=b16(W), bias=b16(bias), **kw)
+    xg = mot.embed_mix(dev(toks), b16(Et), b16(Eb), mode="concat_linear", bpt=bpt, ids_a=dev(pulled), weight=b16(W), bias=b16(bias),
+                       one_launch=tile_kernel, **kw)
     gotg = host(xg.float())
     farg = np.abs(gotg.astype(np.float64) - want) > max(5e-4, float(np.abs(W).max()) * 2.0 ** -5)
     assert ulps(gotg, want)[farg].max(initial=0) <= 2
