@@ -4,20 +4,33 @@
 One "step" = one pass of the hot path over one synthetic batch: tokens (int32, resident in HBM)
 -> token->byte table gather -> pull-from-left -> token/byte embedding gathers -> sum -> rms-norm
 -> x (fp32), i.e. ONE launch of mot_embed_mix_fwd (include/mot.h).  Default workload is
-BASELINE.json configs[3] at one GPU: B x T = 256 x 2048, GPT-2 vocab 50257, bpt 16, d_model 768
-(byte dim 48), FineWeb-shaped ids.  With --gpus N every rank runs the same
-per-GPU batch on its own shard of rows (weak scaling; the path has no data-path collective),
-and the only RCCL traffic is the counter all-reduce after the timed region.
+BASELINE.json configs[3]: B x T = 256 x 2048, GPT-2 vocab 50257, bpt 16, d_model 768 (byte dim
+48), FineWeb-shaped ids.
+
+Multi-GPU (`--gpus N`): one process per GPU.  Started under torchrun (RANK / WORLD_SIZE in the
+environment) the process is one rank; started plainly (`python3 bench.py --gpus N`) the parent
+launches the N ranks itself as child processes BEFORE making any GPU call, and relays rank 0's
+JSON line.  Default for N > 1 is STRONG scaling -- config 4 as BASELINE words it: ONE 256 x 2048
+batch whose rows are split over the ranks exactly as the reference's loader slices them
+(train_gpt.py:795-805) -- `--scaling weak` runs the full batch on every rank instead.  The path
+has no data-path collective; the only RCCL traffic is the all-reduce of the int64[4] byte
+statistics (and of the timings) after the timed region.
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic bytes per launch / average
-launch duration measured with HIP events on the launch stream; `cpu_baseline` = the CPU oracle
-(a C/OpenMP port of the reference path) timed on this host on a bounded sample.
+launch duration measured with HIP events on the launch stream over the timed region (per rank;
+the slowest rank's duration is used); `cpu_baseline` = the CPU oracle (a C/OpenMP port of the
+reference path) timed on this host on a bounded sample; `extra` (N = 1) = the same kernel where
+caches cannot help: uniform ids, a token table larger than the Infinity Cache, the 65 536-token
+shard each GPU sees at 8-way strong scaling.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -35,15 +48,27 @@ WORKLOADS = {
     # name: (B, T, vocab, bpt, d_model, byte_dim, byte_vocab, mode)
     "c4": (256, 2048, 50257, 16, 768, 48, 458, "sum"),     # headline: BASELINE configs[3]
     "c2": (64, 1024, 50257, 16, 768, 48, 458, "sum"),      # configs[1]
-    "c5": (64, 8192, 128256, 8, 2048, 2048, 132, "mean"),  # configs[4] shape family, quarter batch
+    "c4big": (256, 2048, 128256, 16, 768, 48, 458, "sum"),  # the headline kernel over a 394 MB token table (> Infinity Cache)
+    "c5": (256, 8192, 128256, 8, 2048, 2048, 132, "mean"),  # configs[4]: Llama-3 vocab, d 2048, 8 char slots, full batch
+    "c5q": (64, 8192, 128256, 8, 2048, 2048, 132, "mean"),  # a quarter of it (round-1 record)
     # concat + linear mixin (MFMA-bound): (.., d_model, byte_dim, .., mode, token_dim)
     "c2l": (64, 1024, 50257, 16, 768, 32, 458, "concat_linear", 256),     # configs[1] CONCAT dims (K = 768)
     "prodl": (64, 1024, 50257, 16, 1024, 48, 458, "concat_linear", 256),  # experiments100_000steps.sh dims (K = 1024)
 }
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak, MI355X_MICROARCH.md
+# sources whose change invalidates the committed PMC traffic figure of the fused SUM kernel
+TRAFFIC_SOURCES = ("include/mot.h", "mixture-of-tokenizers_amd/csrc/mot_embed.hip", "mixture-of-tokenizers_amd/csrc/mot_mix.hpp",
+                   "mixture-of-tokenizers_amd/csrc/mot_tile.hpp", "mixture-of-tokenizers_amd/csrc/mot_internal.hpp")
 
 
-def parse():
+def source_sha16() -> str:
+    h = hashlib.sha256()
+    for rel in TRAFFIC_SOURCES:
+        h.update((REPO / rel).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -52,32 +77,81 @@ def parse():
     ap.add_argument("--ids", default="fused", choices=["fused", "given"],
                     help="fused: byte ids produced inside the kernel; given: int64 ids precomputed (module-level path)")
     ap.add_argument("--uniform-ids", action="store_true", help="uniform token ids (no-reuse worst case)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="weak (default): every rank runs the full per-GPU batch; strong: the workload's B rows are split over the ranks "
-                         "(config 4 as worded: one 256x2048 batch sharded over the GPUs, train_gpt.py:795-805)")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="strong (default for --gpus > 1): the workload's B rows are split over the ranks (config 4 as worded: one "
+                         "256x2048 batch sharded over the GPUs, train_gpt.py:795-805); weak: every rank runs the full batch")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="table/output element type (compute is fp32)")
     ap.add_argument("--backward", action="store_true", help="also time the backward launch (sum workloads) and report it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary records (uniform ids, table > Infinity Cache, 65 536-token shard)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous / aggregation only: gloo on the CPU, no GPU call, no kernel (CPU tests of the N-rank path)")
+    args = ap.parse_args(argv)
+    if args.scaling is None:
+        args.scaling = "strong" if args.gpus > 1 else "weak"
+    return args
 
 
-def make_inputs(wl, device, seed, uniform, rows=None):
+# ------------------------------------------------------------------------------------------------
+# self-launch: `python3 bench.py --gpus N` without torchrun
+# ------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args, argv) -> int:
+    """Parent of a plain `--gpus N` run: starts the N ranks as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+    their environment, as torchrun would) and relays rank 0's JSON line.  Nothing here touches the GPU: torch is imported but
+    no HIP call is made in this process (device_count() does not initialise the runtime on this image)."""
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} visible", file=sys.stderr)
+            return 2
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(args.gpus),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    for ln in (out0 or "").splitlines():     # the contract is ONE JSON line on stdout: library chatter of rank 0 goes to stderr
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(rcs) if c]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def make_inputs(wl, device, seed, uniform, rows=None, row0=0, vocab_override=None):
+    """Synthetic inputs of one rank: `rows` rows starting at global row `row0` of the seeded batch (strong scaling slices one
+    global batch, as the loader's rank slice does)."""
     import golden_inputs as gi
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
-    B = rows or B
+    vocab = vocab_override or vocab
+    rows = rows or B
     Dt = WORKLOADS[wl][8] if mode == "concat_linear" else D
-    g = torch.Generator(device=device).manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(12345)                       # tables are replicated: same on every rank
     tok_table = torch.randn((vocab, Dt), generator=g, device=device, dtype=torch.float32)
     byte_table = torch.randn((Vb, Db), generator=g, device=device, dtype=torch.float32)
     if mode in ("sum", "concat_linear"):
         try:
             tab = gi.widen_left_pad(gi.load_real_ttb8(), bpt)     # real GPT-2 token->char table (data fixture)
             ttb_kind = "gpt2 ttb_8_left_pad widened to 16"
+            if vocab > tab.shape[0]:                               # larger synthetic vocabulary: the real rows, repeated
+                tab = np.concatenate([tab] * (-(-vocab // tab.shape[0])))[:vocab]
+                ttb_kind += f", tiled to {vocab} rows"
         except FileNotFoundError:
             tab = gi.synth_ttb(5, vocab, bpt, "left")
             ttb_kind = "synthetic"
-        toks = gi.fineweb_like_tokens(seed, B, T, vocab=vocab, uniform=uniform)
+        toks = gi.fineweb_like_tokens(seed, row0 + rows, T, vocab=vocab, uniform=uniform)[row0:]
         weight = None
         if mode == "concat_linear":
             K = Dt + bpt * Db
@@ -85,8 +159,8 @@ def make_inputs(wl, device, seed, uniform, rows=None):
             weight = (torch.rand((D, K), generator=g, device=device, dtype=torch.float32) * 2 - 1) * bound
         return dict(toks=toks, tab=tab, tok_table=tok_table, byte_table=byte_table, ttb_kind=ttb_kind, weight=weight)
     rs = np.random.RandomState(seed)
-    toks = rs.randint(0, vocab, size=(B, T)).astype(np.int32)
-    chars = rs.randint(0, Vb, size=(B, T * bpt)).astype(np.int64)
+    toks = rs.randint(0, vocab, size=(row0 + rows, T)).astype(np.int32)[row0:]
+    chars = rs.randint(0, Vb, size=(row0 + rows, T * bpt)).astype(np.int64)[row0:]
     return dict(toks=toks, chars=chars, tok_table=tok_table, byte_table=byte_table, ttb_kind="n/a")
 
 
@@ -124,7 +198,7 @@ def cpu_baseline(wl, inp, seconds):
     cores = usable_cores()
     orc.set_threads(cores)
     Et, Eb = inp["tok_table"].float().cpu().numpy(), inp["byte_table"].float().cpu().numpy()
-    rows = min(B, 32)
+    rows = min(len(inp["toks"]), 32 if mode != "mean" else 4)
     toks = inp["toks"][:rows]
 
     def once():
@@ -155,11 +229,88 @@ def cpu_baseline(wl, inp, seconds):
                        f"(oracle/calibrate_cpu.py, 8 threads): this port runs 8.3x FASTER than the reference's own eager-PyTorch CPU path")
 
 
-def main():
-    args = parse()
+def timed_launches(step, n, warm=5):
+    """Average duration (ms) of n back-to-back launches of `step`, HIP events on the current (launch) stream."""
+    for _ in range(warm):
+        step()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def extra_records(mot, device, dtype, steps):
+    """The headline kernel where caches cannot carry it (N = 1 only, outside the timed region): each record is the same
+    fused SUM launch with its own algorithmic bytes / HIP-event time."""
+    recs = {}
+    cases = (("c4_uniform_ids", "c4", True, None, "no token id repeats inside L2's reach: every row fetch goes to Infinity Cache / HBM"),
+             ("c4_table_394MB", "c4big", False, None, "token table 128 256 x 768 fp32 = 394 MB > the 256 MiB Infinity Cache"),
+             ("c4_table_394MB_uniform_ids", "c4big", True, None, "the same table, uniform ids: neither L2 nor Infinity Cache can hold the rows"),
+             ("shard_65536_tokens", "c4", False, 32, "32 x 2048 tokens: what each GPU runs at 8-way strong scaling of config 4"))
+    for name, wl, uniform, rows, why in cases:
+        B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
+        inp = make_inputs(wl, device, seed=12345, uniform=uniform, rows=rows)
+        rows = rows or B
+        tdt = torch.float32 if dtype == "f32" else torch.bfloat16
+        tt, bt = inp["tok_table"].to(tdt), inp["byte_table"].to(tdt)
+        toks, tab = torch.from_numpy(inp["toks"]).to(device), torch.from_numpy(inp["tab"]).to(device)
+        out = torch.empty((rows, T, D), dtype=tdt, device=device)
+        plan = mot.embed_mix_plan(toks, tt, bt, mode="sum", bpt=bpt, ttb=tab, pull="left", norm_out=True, out=out)
+        ms = timed_launches(plan, max(20, steps // 4))
+        nbytes = algorithmic_bytes_per_token(wl, "fused", 4 if dtype == "f32" else 2) * rows * T
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        recs[name] = {"kernel_ms": ms, "tokens_per_s": rows * T / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                      "tokens_per_launch": rows * T, "why": why}
+        del inp, tt, bt, out, plan
+        torch.cuda.empty_cache()
+    return recs
+
+
+def dry_run(args, world, rank):
+    """N-rank launcher / rendezvous / aggregation without a GPU: gloo on the CPU, the same barrier + max-over-ranks +
+    counter all-reduce sequence as the real run, a synthetic step."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    B, T = WORKLOADS[args.workload][:2]
+    if args.scaling == "strong":
+        assert B % world == 0, "batch_size % world_size == 0 (train_gpt.py:795)"
+        B //= world
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    elapsed = max(time.perf_counter() - t0, 1e-9)
+    counters = torch.tensor([B * T, B * T * WORKLOADS[args.workload][3], 0, 0], dtype=torch.int64)
+    if world > 1:
+        dist.barrier()
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counters, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({"metric": "mixed-embed tokens/sec at BxT=256x2048; achieved HBM GB/s vs peak", "value": None, "unit": "tokens/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": args.scaling, "dry_run": True,
+                          "config": {"workload": f"{args.workload}: BxT={B}x{T} per rank", "global_tokens_per_step": int(counters[0])},
+                          "byte_stats": {"tokens": int(counters[0]), "slots": int(counters[1])}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, argv))       # parent: no GPU call has been made in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        return dry_run(args, world, rank)
     # MOT_FORCE_DIST=1 exercises the multi-rank code path (RCCL init, barrier, all-reduce) with a single rank
     use_dist = world > 1 or os.environ.get("MOT_FORCE_DIST") == "1"
     if use_dist:
@@ -168,18 +319,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
     import mixture_of_tokenizers_amd as mot
     wl = args.workload
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
+    row0 = 0
     if args.scaling == "strong":
         assert B % world == 0, "batch_size % world_size == 0 (train_gpt.py:795)"
         B //= world
-    inp = make_inputs(wl, device, seed=12345 + rank, uniform=args.uniform_ids, rows=B)   # loader default seed, train_gpt.py:661
-    toks = torch.from_numpy(inp["toks"]).to(device)
+        row0 = rank * B                                    # rank r owns rows [r*B/W, (r+1)*B/W) of the one global batch
+    # loader default seed (train_gpt.py:661); weak scaling: every rank draws its own full batch
+    inp = make_inputs(wl, device, seed=12345 + (rank if args.scaling == "weak" else 0), uniform=args.uniform_ids, rows=B, row0=row0)
+    toks = torch.from_numpy(np.ascontiguousarray(inp["toks"])).to(device)
     esize = 4
     if args.dtype == "bf16":
         esize = 2
@@ -195,11 +348,9 @@ def main():
         else:
             from mixture_of_tokenizers_amd import data_creation as dc
             ids = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
-
             kwf = dict(mode="sum", bpt=bpt, ids_a=ids, norm_out=True, out=out)
     elif mode == "concat_linear":
         tab = torch.from_numpy(inp["tab"]).to(device)
-
         if args.ids == "fused":
             kwf = dict(mode="concat_linear", bpt=bpt, ttb=tab, pull="left", weight=inp["weight"], norm_tok=True, norm_byte=True,
                        norm_out=True, out=out)
@@ -208,17 +359,16 @@ def main():
             ids = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
             kwf = dict(mode="concat_linear", bpt=bpt, ids_a=ids, weight=inp["weight"], norm_tok=True, norm_byte=True, norm_out=True, out=out)
     else:
-        chars = torch.from_numpy(inp["chars"]).to(device)
+        chars = torch.from_numpy(np.ascontiguousarray(inp["chars"])).to(device)
         lt, lc = torch.tensor(1.0, device=device), torch.tensor(0.5, device=device)
-
         kwf = dict(mode="mean", bpt=bpt, ids_a=chars, scale_tok=lt, scale_byte=lc, out=out)
 
     # one bound descriptor per variant: a step is exactly one mot_embed_mix_fwd call on the current stream
     plan = mot.embed_mix_plan(toks, inp["tok_table"], inp["byte_table"], **kwf)
-    plan_cnt = mot.embed_mix_plan(toks, inp["tok_table"], inp["byte_table"], counters=counters, **kwf)
+    plan_cnt = None if mode == "mean" else mot.embed_mix_plan(toks, inp["tok_table"], inp["byte_table"], counters=counters, **kwf)
 
-    def step(cnt=None):
-        (plan if cnt is None else plan_cnt)()
+    def step():
+        plan()
 
     def barrier():
         if use_dist:
@@ -259,32 +409,43 @@ def main():
         c1.record(); torch.cuda.synchronize()
         copy_gbs = 2 * src.numel() * 4 * 10 / (c0.elapsed_time(c1) * 1e-3) / 1e9
         del src, dst
-    step(counters)                                          # statistics pass, outside the timed region
+    if plan_cnt is not None:
+        plan_cnt()                                          # statistics pass, outside the timed region
     torch.cuda.synchronize()
     mot.check_status()
 
     tokens_per_step = B * T
+    kernel_ms_ranks = [kernel_ms]
     if use_dist:
         import torch.distributed as dist
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)     # the path's only collective: <= 64 B over RCCL/xGMI
-        kms = torch.tensor([kernel_ms], dtype=torch.float64, device=device)
-        dist.all_reduce(kms, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms = float(tmax.item()), float(kms.item())
+        kall = torch.zeros(world, dtype=torch.float64, device=device)
+        kall[rank] = kernel_ms
+        dist.all_reduce(kall, op=dist.ReduceOp.SUM)
+        kernel_ms_ranks = kall.tolist()
+        elapsed, kernel_ms = float(tmax.item()), max(kernel_ms_ranks)
     total_tokens = tokens_per_step * world * args.steps
 
     if rank == 0:
         bpt_alg = algorithmic_bytes_per_token(wl, args.ids, esize)
         launch_bytes = bpt_alg * tokens_per_step
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_note = None, "no PMC record for this workload"
         tfile = REPO / "profiles" / "traffic.json"
-        if tfile.exists():
+        if tfile.exists() and world == 1:
             try:
-                traffic = json.loads(tfile.read_text()).get(f"{wl}_{args.ids}")
-            except Exception:
-                traffic = None
+                tj = json.loads(tfile.read_text())
+                key = f"{wl}_{args.ids}" + ("" if args.dtype == "f32" else "_bf16") + ("_uniform" if args.uniform_ids else "")
+                det = tj.get(key + "_detail", {})
+                if key in tj and det.get("source_sha16") == source_sha16():
+                    traffic, traffic_note = tj[key], f"rocprofv3 --pmc passes, {det.get('profile')}, kernel sources {det.get('source_sha16')}"
+                elif key in tj:
+                    traffic_note = (f"profiles/traffic.json[{key}] was measured on kernel sources {det.get('source_sha16')}, the tree is at "
+                                    f"{source_sha16()}: refused as stale (re-run tools/pmc_traffic.sh)")
+            except Exception as exc:    # a malformed file is not a reason to lose the bench line
+                traffic_note = f"profiles/traffic.json unreadable: {exc}"
         c = counters.tolist()
         res = {
             "metric": "mixed-embed tokens/sec at BxT=256x2048; achieved HBM GB/s vs peak",
@@ -294,14 +455,18 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16 tables/output, f32 arithmetic", "data": "synthetic",
-            "config": {"workload": f"{wl}: BxT={B}x{T} per GPU, vocab {vocab}, bpt {bpt}, d_model {D}, byte_dim {Db}, "
-                                   f"mode {mode}+rmsnorm, ids {args.ids}, token ids "
-                                   f"{'uniform' if args.uniform_ids else 'FineWeb-shaped (u^3 skew, EOT p=1/700)'}, "
+            "config": {"workload": f"{wl}: BxT={B}x{T} per GPU"
+                                   + (f" (rows {row0}..{row0 + B - 1} of one {B * world}x{T} batch)" if args.scaling == "strong" and world > 1 else "")
+                                   + f", vocab {vocab}, bpt {bpt}, d_model {D}, byte_dim {Db}, "
+                                   f"mode {mode}{'+rmsnorm' if mode != 'mean' else ''}, ids {args.ids}, token ids "
+                                   f"{'uniform' if args.uniform_ids or mode == 'mean' else 'FineWeb-shaped (u^3 skew, EOT p=1/700)'}, "
                                    f"ttb {inp['ttb_kind']}",
                        "global_tokens_per_step": tokens_per_step * world, "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "embed_mix_kernel", "kernel_ms": kernel_ms, "launch_us": launch_us,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": "embed_mean_lds_kernel" if mode == "mean" else "embed_mix_kernel", "kernel_ms": kernel_ms, "launch_us": launch_us,
+                         "per": "rank (slowest rank's launch time; every rank moves the same algorithmic bytes)",
+                         "kernel_ms_per_rank": kernel_ms_ranks, "aggregate_GBps": achieved * world,
                          "device_copy_GBps": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "algorithmic_bytes_per_token": bpt_alg, "tokens_per_launch": tokens_per_step},
             "byte_stats": {"tokens": c[0], "slots": c[1], "pads_before": c[2], "pads_after": c[3],
@@ -328,15 +493,7 @@ def main():
                     "byte_table": torch.zeros_like(inp["byte_table"], dtype=torch.float32)}
             bstep = lambda: mot.functional.embed_mix_backward(gout, toks, inp["tok_table"], inp["byte_table"], mode="sum",
                                                                bpt=bpt, ids_a=ids_b, norm_out=True, into=into)
-            for _ in range(3):
-                bstep()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            nb = max(1, args.steps // 4)
-            for _ in range(nb):
-                bstep()
-            e1.record(); torch.cuda.synchronize()
-            bms = e0.elapsed_time(e1) / nb
+            bms = timed_launches(bstep, max(1, args.steps // 4), warm=3)
             read_bytes = 2 * out.element_size() * D * tokens_per_step   # grad_out row + token row per position (byte rows and ids come from L2)
             res["backward"] = {"kernel": "embed_mix_bwd_full_kernel", "kernel_ms": bms, "tokens_per_s": tokens_per_step / (bms * 1e-3),
                                "hbm_read_GBps": read_bytes / (bms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
@@ -344,6 +501,10 @@ def main():
                                        "then one scatter kernel -- a token row is read and its gradient row flushed (fp32 atomic "
                                        "row-add) once per run, byte-table gradient in 64-bit fixed point in LDS; hbm_read counts the "
                                        "algorithmic grad_out row + token row per position"}
+        if world == 1 and mode == "sum" and wl == "c4" and args.ids == "fused" and not args.uniform_ids and not args.no_extra:
+            del plan, plan_cnt, out
+            torch.cuda.empty_cache()
+            res["extra"] = extra_records(mot, device, args.dtype, args.steps)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, inp, args.cpu_seconds)
         print(json.dumps(res), flush=True)

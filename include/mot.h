@@ -112,6 +112,23 @@ int mot_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *tt
                      mot_stream_t stream);
 
 /*
+ * Replaces TokenMixByCharStreamingDataset.chr_tokenize + create_char_matrix     inference/inference.py:56-67, 79-96
+ * (the producer of the character ids of BASELINE config 5; a host-side Python loop in the reference), for a batch of
+ * sequences in one launch.
+ *   seq_offsets int64 [n_seqs + 1]: entries (one per BPE token, in order) of sequence s are [seq_offsets[s], seq_offsets[s+1])
+ *   tok_offsets int64 [n_entries + 1]: code points of entry e are codes[tok_offsets[e] .. tok_offsets[e+1])
+ *   codes       int32: Unicode code points of the token strings (chr_tokenize's `ord(x)`); a NEGATIVE value c is a literal
+ *               character id -c - 1 (the [129] row get_tokens prepends for BOS, line 73, is passed as -130)
+ *   out         int64 [n_seqs, seq_len, max_char]: ids 0-127 ASCII, 128 the tokenizer's leading-space marker, 129 / 130 a
+ *               code point equal to the BOS / EOS token id (the reference compares ord(x) with the TOKEN ids, lines 62-65),
+ *               131 any other character; one end-of-word 130 after the last character of a row that is not full; 2 elsewhere
+ *               (line 82) and on rows past the sequence's entries; characters beyond max_char are dropped (lines 89-91).
+ */
+int mot_char_matrix(const int32_t *codes, const int64_t *tok_offsets, const int64_t *seq_offsets, int64_t n_seqs,
+                    int64_t seq_len, int max_char, int32_t leading_space, int32_t bos_token_id, int32_t eos_token_id,
+                    int64_t *out, mot_stream_t stream);
+
+/*
  * Replaces emb(ids) / norm(emb(ids)) / norm(emb(ids_a) + emb(ids_b)) when the caller wants the
  * tensors at the FlexibleEmbedding seam materialised
  *                                                 scaled-pre-train/train_gpt.py:342-379, 172-173

@@ -37,7 +37,7 @@ def dtype_code(t: torch.dtype) -> int:
 
 EXPORTS = (
     "mot_version", "mot_last_error", "mot_build_info", "mot_tokens_to_bytes", "mot_pull_bytes",
-    "mot_create_batch", "mot_gather_rows", "mot_embed_mix_desc_size", "mot_embed_mix_workspace_bytes",
+    "mot_create_batch", "mot_char_matrix", "mot_gather_rows", "mot_embed_mix_desc_size", "mot_embed_mix_workspace_bytes",
     "mot_embed_mix_fwd", "mot_embed_mix_bwd_workspace_bytes", "mot_embed_mix_bwd",
     "mot_cross_attn_desc_size", "mot_cross_attn_workspace_bytes", "mot_cross_attn_fwd",
     "mot_cross_attn_bwd_workspace_bytes", "mot_cross_attn_bwd",
@@ -111,6 +111,7 @@ def _load() -> C.CDLL:
     lib.mot_tokens_to_bytes.argtypes = [vp, i64, vp, i32, i64, i32, vp, vp, vp]
     lib.mot_pull_bytes.argtypes = [vp, vp, i64, i64, i32, i64, i64, i32, vp]
     lib.mot_create_batch.argtypes = [vp, i64, i64, vp, vp, i32, i64, i32, i64, i64, vp, vp, vp]
+    lib.mot_char_matrix.argtypes = [vp, vp, vp, i64, i64, i32, i32, i32, i32, vp, vp]
     lib.mot_gather_rows.argtypes = [vp, vp, i32, i64, vp, i64, i32, i32, f32, vp, vp, vp, i32, vp]
     lib.mot_embed_mix_desc_size.restype = C.c_size_t
     lib.mot_embed_mix_workspace_bytes.restype = C.c_size_t
@@ -128,7 +129,7 @@ def _load() -> C.CDLL:
     lib.mot_cross_attn_bwd_workspace_bytes.argtypes = [C.POINTER(MotCrossAttnDesc)]
     lib.mot_cross_attn_bwd.argtypes = [C.POINTER(MotCrossAttnDesc), C.POINTER(MotCrossAttnGrads), vp]
     lib.mot_cross_attn_bwd.restype = C.c_int
-    for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_gather_rows", "mot_embed_mix_fwd",
+    for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_char_matrix", "mot_gather_rows", "mot_embed_mix_fwd",
                  "mot_embed_mix_bwd"):
         getattr(lib, name).restype = C.c_int
     if lib.mot_version() != ABI_VERSION:

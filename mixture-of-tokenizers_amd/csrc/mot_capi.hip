@@ -153,6 +153,16 @@ int mot_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *tt
                                (int32_t)eot_byte, out, status, (hipStream_t)stream);
 }
 
+int mot_char_matrix(const int32_t *codes, const int64_t *tok_offsets, const int64_t *seq_offsets, int64_t n_seqs, int64_t seq_len, int max_char,
+                    int32_t leading_space, int32_t bos_token_id, int32_t eos_token_id, int64_t *out, mot_stream_t stream) {
+    if (n_seqs < 0 || seq_len < 0) return set_error(MOT_ESHAPE, "char_matrix: negative shape");
+    if (max_char < 1 || max_char > MOT_MAX_BPT) return set_error(MOT_EUNSUPPORTED, "char_matrix: max_char %d outside [1, %d]", max_char, MOT_MAX_BPT);
+    if (n_seqs == 0 || seq_len == 0) return MOT_OK;
+    if (!tok_offsets || !seq_offsets || !out) return set_error(MOT_EINVAL, "char_matrix: null pointer");   // codes may be NULL when every entry is empty
+    return launch_char_matrix(codes, tok_offsets, seq_offsets, n_seqs, seq_len, max_char, leading_space, bos_token_id, eos_token_id, out,
+                              (hipStream_t)stream);
+}
+
 int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, int64_t n, const void *table, int64_t rows,
                     int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int dtype,
                     mot_stream_t stream) {

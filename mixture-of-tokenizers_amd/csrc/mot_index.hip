@@ -114,6 +114,52 @@ __global__ __launch_bounds__(kThreads) void create_batch_kernel(const int32_t *_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Character matrix of the Llama front-end (inference/inference.py): chr_tokenize (56-67) + create_char_matrix (79-96).
+// Sequence s owns the entries [seq_off[s], seq_off[s+1]) (one per BPE token, in order); entry e owns the code points
+// codes[tok_off[e] .. tok_off[e+1]).  Row r of the matrix = entry seq_off[s] + r: its first max_char characters mapped to
+// ids (ASCII as is, the tokenizer's leading-space marker -> 128, a code point equal to the BOS / EOS token id -> 129 /
+// 130, anything else -> 131; a NEGATIVE code c is a literal id -c - 1, e.g. the [129] row get_tokens prepends, line 73),
+// then ONE end-of-word id 130 if the row is not full, the rest (and every row past the entries) 2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void char_matrix_kernel(const int32_t *__restrict__ codes, const int64_t *__restrict__ tok_off,
+                                                               const int64_t *__restrict__ seq_off, int64_t n_seqs, int64_t seq_len, int max_char,
+                                                               int32_t leading_space, int32_t bos_id, int32_t eos_id, int64_t *__restrict__ out) {
+    const int64_t total = n_seqs * seq_len * max_char;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int k = (int)(i % max_char);
+        const int64_t rr = i / max_char, r = rr % seq_len, s = rr / seq_len;
+        const int64_t e = seq_off[s] + r;
+        int64_t v = 2;                                            // "Initialize character matrices with 2: EOS/PAD", line 82
+        if (e < seq_off[s + 1]) {
+            const int64_t c0 = tok_off[e], len = tok_off[e + 1] - c0;
+            if (k < len) {                                        // characters beyond max_char are dropped, lines 89-91
+                const int32_t c = codes[c0 + k];
+                if (c < 0) v = -(int64_t)c - 1;
+                else if (c <= 127) v = c;
+                else if (c == leading_space) v = 128;
+                else if (c == bos_id) v = 129;
+                else if (c == eos_id) v = 130;
+                else v = 131;
+            } else if (k == len) {
+                v = 130;                                          // "ONE EOW TOKEN IS 130 THEN 2", lines 80, 94-95
+            }
+        }
+        out[i] = v;
+    }
+}
+
+int launch_char_matrix(const int32_t *codes, const int64_t *tok_off, const int64_t *seq_off, int64_t n_seqs, int64_t seq_len, int max_char,
+                       int32_t leading_space, int32_t bos_id, int32_t eos_id, int64_t *out, hipStream_t stream) {
+    const int64_t total = n_seqs * seq_len * max_char;
+    if (total == 0) return MOT_OK;
+    int64_t blocks = (total + kThreads - 1) / kThreads;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(char_matrix_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, codes, tok_off, seq_off, n_seqs, seq_len, max_char,
+                       leading_space, bos_id, eos_id, out);
+    return check_launch("char_matrix_kernel");
+}
+
 // ------------------------------------------------------------------------------------------ launchers
 int pick_tile_tokens(int64_t n_rows, int64_t tokens_per_row, int bpt, bool with_ids) {
     // Largest tile that still gives >= ~2048 workgroups (8 per CU) and <= 64 KB of LDS.

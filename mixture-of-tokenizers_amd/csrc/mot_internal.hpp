@@ -27,6 +27,8 @@ int launch_pull_bytes(const int64_t *in, int64_t *out, int64_t B, int64_t tokens
 int launch_create_batch(const int32_t *tokens, int64_t B, int64_t T, const void *ttb_left, const void *ttb_right,
                         int elem, int64_t ttb_rows, int bpt, int32_t pad, int32_t eot, int64_t *out, uint32_t *status,
                         hipStream_t stream);
+int launch_char_matrix(const int32_t *codes, const int64_t *tok_off, const int64_t *seq_off, int64_t n_seqs, int64_t seq_len, int max_char,
+                       int32_t leading_space, int32_t bos_id, int32_t eos_id, int64_t *out, hipStream_t stream);
 int launch_gather_rows(const void *ids_a, const void *ids_b, int ids_elem, int64_t n, const void *table, int64_t rows,
                        int dim, int rms_norm, float eps, const float *scale, void *out, uint32_t *status, int dtype,
                        hipStream_t stream);

@@ -131,3 +131,62 @@ def tokens_to_digits(tokens: torch.Tensor, digit_table: torch.Tensor) -> torch.T
     (moved to the tokens' device by the caller, like the token->byte table)."""
     out = F_mot.tokens_to_bytes(tokens.to(torch.int32), digit_table)
     return out.view(-1) if tokens.ndim == 1 else out.view(tokens.shape[0], -1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Llama character front-end (inference/inference.py): the producer of config 5's character ids
+# ------------------------------------------------------------------------------------------------
+class CharTokenizer:
+    """``chr_tokenize`` / ``create_char_matrix`` of TokenMixByCharStreamingDataset (inference.py:46-96) without the HF
+    tokenizer object: its three tokenizer-dependent constants are arguments (Llama-3 defaults: the byte-level BPE's
+    leading-space marker "Ġ" = 288, bos_token_id 128000, eos_token_id 128001).  The BPE tokenisation itself
+    (``get_tokens``, lines 69-77: AutoTokenizer) stays with the caller -- it needs the tokenizer files.
+
+    Character ids: 0-127 ASCII, 128 leading space, 129 BOS, 130 EOS / end-of-word, 131 other; 2 = fill (line 82)."""
+
+    def __init__(self, num_char_positions: int = 8, leading_space_ind: int = 288, bos_token_id: int = 128000,
+                 eos_token_id: int = 128001):
+        self.max_char = int(num_char_positions)
+        self.leading_space_ind, self.bos_token_id, self.eos_token_id = int(leading_space_ind), int(bos_token_id), int(eos_token_id)
+
+    def chr_tokenize(self, x: str) -> int:          # inference.py:56-67 (host, one character; the batch path maps on the device)
+        ind = ord(x)
+        if ind <= 127:
+            return ind
+        if ind == self.leading_space_ind:
+            return 128
+        if ind == self.bos_token_id:
+            return 129
+        if ind == self.eos_token_id:
+            return 130
+        return 131
+
+    def _launch(self, codes, tok_off, seq_off, n_seqs, seq_len, device) -> torch.Tensor:
+        dev = torch.device(device)
+        c = torch.tensor(codes if len(codes) else [0], dtype=torch.int32).to(dev)
+        to, so = torch.tensor(tok_off, dtype=torch.int64).to(dev), torch.tensor(seq_off, dtype=torch.int64).to(dev)
+        return F_mot.char_matrix(c, to, so, n_seqs, seq_len, self.max_char, self.leading_space_ind, self.bos_token_id, self.eos_token_id)
+
+    def create_char_matrix(self, char_tokens, seq_len: int, device="cuda") -> torch.Tensor:
+        """inference.py:79-96: ``char_tokens`` = one list of character IDS per token (what get_tokens returns) ->
+        (seq_len, max_char) int64, as the reference's ``create_char_matrix(...).long()``."""
+        codes, off = [], [0]
+        for sub in char_tokens:
+            codes.extend(-int(v) - 1 for v in sub)              # literal ids
+            off.append(len(codes))
+        return self._launch(codes, off, [0, len(char_tokens)], 1, seq_len, device)[0]
+
+    def char_matrix_from_tokens(self, token_strings, seq_len: int, bos: bool = True, device="cuda") -> torch.Tensor:
+        """get_tokens' character side (lines 72-76) + create_char_matrix for a BATCH of sequences in one launch:
+        ``token_strings`` = per sequence, the tokenizer's token strings; ``bos`` prepends the [129] row of line 73.
+        Code points travel to the device as they are; chr_tokenize runs there."""
+        codes, toff, soff = [], [0], [0]
+        for seq in token_strings:
+            if bos:
+                codes.append(-130)                                # literal id 129
+                toff.append(len(codes))
+            for tok in seq:
+                codes.extend(ord(ch) for ch in tok)
+                toff.append(len(codes))
+            soff.append(len(toff) - 1)
+        return self._launch(codes, toff, soff, len(token_strings), seq_len, device)

@@ -107,6 +107,20 @@ def create_batch(tokens: torch.Tensor, table_left: torch.Tensor, table_right: to
 
 
 @torch.compiler.disable
+def char_matrix(codes: torch.Tensor, tok_offsets: torch.Tensor, seq_offsets: torch.Tensor, n_seqs: int, seq_len: int, max_char: int,
+                leading_space: int, bos_token_id: int, eos_token_id: int) -> torch.Tensor:
+    """(n_seqs, seq_len, max_char) int64 character ids (inference.py:56-67, 79-96); see mot_char_matrix in include/mot.h."""
+    dev = capi.require_device(codes, tok_offsets, seq_offsets)
+    c, to, so = _contig(codes, torch.int32, "codes"), _contig(tok_offsets, torch.int64, "tok_offsets"), _contig(seq_offsets, torch.int64, "seq_offsets")
+    if so.numel() != n_seqs + 1:
+        raise ValueError("seq_offsets must hold n_seqs + 1 entries")
+    out = torch.empty((n_seqs, seq_len, max_char), dtype=torch.int64, device=dev)
+    capi.check(capi.lib.mot_char_matrix(capi.ptr(c), capi.ptr(to), capi.ptr(so), int(n_seqs), int(seq_len), int(max_char), int(leading_space),
+                                        int(bos_token_id), int(eos_token_id), capi.ptr(out), capi.stream_of(dev)))
+    return out
+
+
+@torch.compiler.disable
 def gather_rows(table: torch.Tensor, ids: torch.Tensor, ids_b: torch.Tensor | None = None, *, rms_norm: bool = False,
                 eps: float | None = None, scale: torch.Tensor | None = None) -> torch.Tensor:
     """scale * rms_norm?(table[ids] (+ table[ids_b])) -> ids.shape + (dim,)  (train_gpt.py:342-379)."""

@@ -319,3 +319,39 @@ def cross_attn_bwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_
               _p(out["tok_table"], C.c_double), _p(out["byte_table"], C.c_double), _p(out["q_w"], C.c_double),
               _p(out["kv_w"], C.c_double), _p(out["proj_w"], C.c_double), _p(out["lambda_factor"], C.c_double)), "cross_attn_bwd")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Llama character front-end (config 5).  PARITY UNPINNED: inference/inference.py cannot be imported offline (hub login at
+# line 34, from_pretrained at 52); these are line-by-line restatements checked against hand-derived vectors only.
+# ----------------------------------------------------------------------------------------------
+def chr_tokenize(x: str, leading_space_ind: int = 288, bos_token_id: int = 128000, eos_token_id: int = 128001) -> int:
+    """inference/inference.py:56-67."""
+    ind = ord(x)
+    if ind <= 127:                      # ascii
+        return ind
+    if ind == leading_space_ind:        # leading character for token
+        return 128
+    if ind == bos_token_id:             # BOS
+        return 129
+    if ind == eos_token_id:             # EOS/PAD
+        return 130
+    return 131                          # unicode past 128
+
+
+def create_char_matrix(char_tokens, seq_len: int, max_char: int = 8) -> np.ndarray:
+    """inference/inference.py:79-96 (+ the .long() of line 102): rows of 2, the row's characters (truncated at max_char),
+    one 130 after them when the row is not full."""
+    mat = np.zeros((seq_len, max_char), dtype=np.float32) + 2
+    for row, sublist in enumerate(char_tokens):
+        if row >= seq_len:
+            break
+        ind = 0
+        for char in sublist:
+            if ind >= max_char:
+                break
+            mat[row][ind] = char
+            ind += 1
+        if ind < max_char:
+            mat[row][ind] = 130
+    return mat.astype(np.int64)

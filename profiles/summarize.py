@@ -14,6 +14,7 @@ import collections, csv, glob, json, sys
 from pathlib import Path
 
 HERE = Path(__file__).resolve().parent
+sys.path.insert(0, str(HERE.parent))
 
 
 def main():
@@ -48,7 +49,9 @@ def main():
         t[key] = int(2 * fetch * 1024 + write * 1024)
         t[key + "_detail"] = {"kernel": kern, "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write,
                               "fetch_bytes_corrected_x2": int(2 * fetch * 1024), "write_bytes": int(write * 1024),
-                              "profile": f"profiles/{tag}_pmc.json"}
+                              "profile": f"profiles/{tag}_pmc.json",
+                              # bench.py refuses the figure once the kernel's sources differ from what was profiled
+                              "source_sha16": __import__("bench").source_sha16()}
         tfile.write_text(json.dumps(t, indent=1) + "\n")
         print(key, t[key])
 

@@ -13,7 +13,7 @@ import torch
 
 import golden_inputs as gi
 from oracle import oracle as orc
-from util_gpu import DEV, dev, f32, host
+from util_gpu import DEV, dev, f32, host, rel
 
 pytestmark = pytest.mark.gpu
 G = gi.GOLDEN_DIR
@@ -113,9 +113,7 @@ def test_cross_attn_errors(mot):
 GTOL = 5e-5
 
 
-def grel(got, ref):
-    ref = np.asarray(ref, dtype=np.float64)
-    return np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+grel = rel   # self-describing on failure (util_gpu.RelErr)
 
 
 @pytest.mark.parametrize("case", gi.CROSS_CASES[:2], ids=lambda c: c[0])

@@ -15,7 +15,7 @@ import torch
 
 import golden_inputs as gi
 from oracle import oracle as orc
-from util_gpu import DEV, dev, host
+from util_gpu import DEV, dev, host, rel
 
 pytestmark = pytest.mark.gpu
 G = gi.GOLDEN_DIR
@@ -185,9 +185,7 @@ def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
 #     du, partly averaged out by the scatter sums), so 4e-3 of max|ref|;
 #   * .grad on bf16 parameters: additionally one bf16 rounding of each element (2^-8 relative).
 # ------------------------------------------------------------------------------------------------
-def relmax(got, ref):
-    ref = np.asarray(ref, dtype=np.float64)
-    return np.abs(np.asarray(got, dtype=np.float64) - ref).max() / max(np.abs(ref).max(), 1e-30)
+relmax = rel   # self-describing on failure (util_gpu.RelErr)
 
 
 @pytest.mark.parametrize("D,Db,bpt,Vt,B,T,kw,seed", [

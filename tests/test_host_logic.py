@@ -216,3 +216,28 @@ def test_grad_bucket_world_size_2_gloo(tmp_path):
     ref = orc.embed_mix_bwd(toks, pulled, None, Et, Eb, g, mode="sum", bpt=bpt, norm_out=True, dtype=np.float64)
     np.testing.assert_allclose(res["tok"].numpy(), ref["tok_table"] / 2, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(res["byte"].numpy(), ref["byte_table"] / 2, rtol=1e-12, atol=1e-12)
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python3 bench.py --gpus 2` with no torchrun environment: the parent starts both ranks itself (before any GPU call),
+    they rendezvous on 127.0.0.1 (gloo here: --dry-run makes no GPU call and launches no kernel), the counters are
+    all-reduced and rank 0's single JSON line comes back through the parent.  Default for N > 1 is strong scaling: ONE
+    256 x 2048 batch split by rows (train_gpt.py:795-805)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for extra, per_rank_rows, global_tokens in (([], 128, 256 * 2048), (["--scaling", "weak"], 256, 2 * 256 * 2048)):
+        r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3", "--warmup", "1"] + extra,
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["dry_run"] is True and j["steps"] == 3
+        assert j["scaling"] == ("weak" if extra else "strong")
+        assert f"BxT={per_rank_rows}x2048 per rank" in j["config"]["workload"]
+        assert j["byte_stats"]["tokens"] == global_tokens            # summed over both ranks by the all-reduce
+    # under a torchrun-style environment the process is ONE rank and must not spawn: WORLD_SIZE disagreeing with --gpus is an error
+    r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr

@@ -424,3 +424,26 @@ def test_bf16_concat_emulation_vs_reference_eager(case):
     assert 5e-3 < e_ref < 5e-2                      # the reference's eager bf16 error, for the record
     assert e_emu < e_ref / 4
     assert rms(ref - emu) < 1.1 * e_ref and np.abs(ref - emu).max() < 8 * e_ref
+
+
+# ------------------------------------------------------------------------------------------------
+# config 5's character-id producer (inference/inference.py:56-67, 79-96).  PARITY UNPINNED by the reference: the file
+# cannot be imported offline and holds no fixture; the vectors below are derived BY HAND from the source text.
+# ------------------------------------------------------------------------------------------------
+def test_create_char_matrix_hand_vectors():
+    # tokens of "<bos>hi Ġthere": get_tokens prepends [129] for BOS (line 73); "Ġ" (U+0120 = 288) is the leading-space marker
+    char_tokens = [[129], [orc.chr_tokenize(c) for c in "hi"], [orc.chr_tokenize(c) for c in "Ġthere"]]
+    assert char_tokens[1] == [104, 105] and char_tokens[2] == [128, 116, 104, 101, 114, 101]
+    m = orc.create_char_matrix(char_tokens, seq_len=5, max_char=8)
+    assert m.dtype == np.int64 and m.shape == (5, 8)
+    want = np.full((5, 8), 2, dtype=np.int64)                  # line 82: everything starts as 2
+    want[0, :2] = (129, 130)                                    # one character, then ONE end-of-word 130 (lines 80, 94-95)
+    want[1, :3] = (104, 105, 130)
+    want[2, :7] = (128, 116, 104, 101, 114, 101, 130)
+    np.testing.assert_array_equal(m, want)                      # rows 3, 4: no token -> all 2
+    # exactly max_char characters: no room for the end-of-word id; more: truncated (lines 89-91); an empty token: 130 first
+    m = orc.create_char_matrix([[1, 2, 3], [1, 2, 3, 4], [], [7]], seq_len=3, max_char=3)
+    np.testing.assert_array_equal(m, [[1, 2, 3], [1, 2, 3], [130, 2, 2]])          # the 4th entry is past seq_len (lines 85-86)
+    # chr_tokenize: ASCII as is; a code point EQUAL to a special token's id maps to it (the reference compares ord(x) with
+    # the token ids, lines 62-65); everything else 131
+    assert [orc.chr_tokenize(c) for c in ("a", "\x7f", "\x80", "Ġ", chr(128000), chr(128001), "é", "日")] == [97, 127, 131, 128, 129, 130, 131, 131]
