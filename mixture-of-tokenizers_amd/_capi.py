@@ -13,7 +13,7 @@ from pathlib import Path
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libmot_hip.so"
+LIB_PATH = Path(os.environ.get("MOT_DEV_LIB") or (_HERE / "libmot_hip.so"))   # MOT_DEV_LIB: kernel-variant A/B runs (tools/variants.sh)
 
 # ---- enums of include/mot.h
 MOT_OK, MOT_EINVAL, MOT_ESHAPE, MOT_EUNSUPPORTED, MOT_EHIP, MOT_EWORKSPACE = 0, -1, -2, -3, -4, -5

@@ -11,48 +11,97 @@
 //            rms-norm reductions are wave shuffles, the mixed row is written once with
 //            non-temporal 16 B stores.  Algorithmic traffic: 4 + 2*bpt + 4*Dt B read and
 //            4*Dm B written per token; HBM-bound.
-#include "mot_mix.hpp"
+#include <stdlib.h>
+
+#include "mot_wave.hpp"
 
 namespace mot {
 
 // ------------------------------------------------------------------------------------------ fused kernel
-// MODE: MOT_MIX_NOOP / SUM / MEAN.   NCH: float4 chunks per lane (covers Dm <= 256*NCH).
-// U: tokens in flight per wave.
+// MODE: MOT_MIX_NOOP / SUM / MEAN.   NCH: 16-byte chunks per lane (covers Dm <= 64*NCH*VEC).   U: tokens in flight per wave.
+// Every WAVE is on its own (mot_wave.hpp): it owns a unit of A.unit consecutive tokens of one row, produces their byte ids
+// in wave-private LDS and streams them; the four waves of a workgroup share nothing and never meet at a barrier.
+// (105 VGPRs at fp32 / 768 columns: four waves per SIMD.  Forcing the fifth with a launch bound spills into the streaming loop:
+// 471 us instead of 435 at 524 288 tokens.)
 template <int MODE, int NCH, int U, typename T, bool DUAL>
 __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
     const T *tok_table = (const T *)A.tok_table, *byte_table = (const T *)A.byte_table;
-    extern __shared__ int32_t lds[];
-    const bool has_ids = MODE != MOT_MIX_NOOP;
-    const TileLds L = tile_lds_carve(lds, A.tile_tokens, has_ids ? A.bpt : 1, true);
-    const int64_t row = blockIdx.x / A.tiles_per_row;
-    const int64_t t0 = (int64_t)(blockIdx.x % A.tiles_per_row) * A.tile_tokens;
-    const int ntok = (int)min((int64_t)A.tile_tokens, A.T - t0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr bool dual = DUAL;  // two id tensors: emb(padded) + emb(pulled)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_wave[];
+    constexpr bool has_ids = MODE != MOT_MIX_NOOP;
+    constexpr bool dual = DUAL;                   // two id tensors: emb(padded) + emb(pulled)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t unit_id = (int64_t)blockIdx.x * kWaves + wave;
+    if (unit_id >= A.n_units) return;             // no barrier anywhere below: a wave may leave on its own
+    const int64_t row = unit_id / A.units_per_row;
+    const int64_t u0 = (unit_id - row * A.units_per_row) * A.unit;
+    const int ntok = (int)min((int64_t)A.unit, A.T - u0);
+    const int stream_eb = (has_ids && A.id_source == MOT_IDS_FROM_TTB && A.pull_dir != kPullNone) ? A.ttb_elem : 0;
+    const WaveLds W = wave_lds_carve(lds_wave + (size_t)wave * A.wave_lds, A.unit, has_ids ? A.bpt : 0, dual, stream_eb);
 
-    if (!has_ids) {
-        if ((int)threadIdx.x < ntok) L.tok[threadIdx.x] = A.tokens[row * A.T + t0 + threadIdx.x];
-        if (A.counters && threadIdx.x == 0) atomicAdd((unsigned long long *)A.counters, (unsigned long long)ntok);
-        __syncthreads();
-    } else if (A.id_source == MOT_IDS_FROM_TTB) {
-        if (A.pull_dir == kPullLeft) phase1_from_ttb<kPullLeft>(A, L, row, t0, ntok);
-        else if (A.pull_dir == kPullRight) phase1_from_ttb<kPullRight>(A, L, row, t0, ntok);
-        else phase1_from_ttb<kPullNone>(A, L, row, t0, ntok);
+    typedef typename Elem<T>::vec vec_t;          // VEC floats: one 16-byte lane load (4 fp32 / 8 bf16)
+    typedef typename Elem<T>::raw raw_t;
+    constexpr int VEC = Elem<T>::kVec;
+    const int Dm = A.Dt, nchunk = Dm / VEC;
+    bool act[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) act[i] = lane + 64 * i < nchunk;
+    // token rows of a batch of U tokens: lane unit_lane0 + j of `tokv` holds the unit's token j.  The first batch is requested
+    // as soon as the token ids are known -- BEFORE the byte-index pass, which then runs under the rows' flight time instead of
+    // in front of the first HBM request of every wave of a small launch.
+    int tokv = 0, unit_lane0 = 0;
+    raw_t ar[U][NCH];
+    auto request_tok_rows = [&](int tb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = min(tb + u, ntok - 1);  // the tail re-reads the last token; its store is skipped
+            int tok = __builtin_amdgcn_readlane(tokv, unit_lane0 + t);   // wave-uniform: the row's address is scalar
+            if ((uint64_t)(uint32_t)tok >= (uint64_t)A.tok_rows) {
+                if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
+                tok = 0;
+            }
+            const T *trow = tok_table + (int64_t)tok * Dm;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) ar[u][i] = Elem<T>::load_raw(trow + VEC * (act[i] ? lane + 64 * i : 0));
+        }
+    };
+    // ---- phase 1: the unit's byte ids into wave-private LDS.  Request order: token ids, their token->byte rows, the first
+    // batch's token rows; the index pass waits for the table rows only (older in the queue than the token rows).
+    auto from_ttb = [&](auto indexer) {
+        tokv = indexer.tokens();
+        unit_lane0 = indexer.unit_lane0;
+        indexer.load_rows();
+#ifndef MOT_VAR_NOPREFETCH      // dev A/B (tools/variants.sh): rows requested after the index pass cost 1.6 us at 65 536 tokens
+        request_tok_rows(0);
+#endif
+        indexer.finish();
+#ifdef MOT_VAR_NOPREFETCH
+        request_tok_rows(0);
+#endif
+    };
+    if (has_ids && A.id_source == MOT_IDS_FROM_TTB) {
+        if (A.ttb_elem == 2) {
+            if (A.pull_dir == kPullLeft) from_ttb(WaveIndexer<kPullLeft, int16_t>(A, W, row, u0, ntok, dual));
+            else if (A.pull_dir == kPullRight) from_ttb(WaveIndexer<kPullRight, int16_t>(A, W, row, u0, ntok, dual));
+            else from_ttb(WaveIndexer<kPullNone, int16_t>(A, W, row, u0, ntok, dual));
+        } else {
+            if (A.pull_dir == kPullLeft) from_ttb(WaveIndexer<kPullLeft, int32_t>(A, W, row, u0, ntok, dual));
+            else if (A.pull_dir == kPullRight) from_ttb(WaveIndexer<kPullRight, int32_t>(A, W, row, u0, ntok, dual));
+            else from_ttb(WaveIndexer<kPullNone, int32_t>(A, W, row, u0, ntok, dual));
+        }
     } else {
-        phase1_given(A, L, row, t0, ntok);
+        tokv = lane < ntok ? A.tokens[row * A.T + u0 + lane] : 0;
+        request_tok_rows(0);
+        if (has_ids) wave_ids_given(A, W, row, u0, ntok);
+        else if (A.counters && lane == 0) atomicAdd((unsigned long long *)A.counters, (unsigned long long)ntok);
     }
 
     // ---- phase 2
-    typedef typename Elem<T>::vec vec_t;          // VEC floats: one 16-byte lane load (4 fp32 / 8 bf16)
-    constexpr int VEC = Elem<T>::kVec;
     const int sv = A.bpt | 1;
-    const int Dm = A.Dt, nchunk = Dm / VEC;
     int slot[NCH], within[NCH];
-    bool act[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = lane + 64 * i;
-        act[i] = c < nchunk;
         const int cc = act[i] ? c : 0;
         if (MODE == MOT_MIX_SUM) {
             slot[i] = (VEC * cc) / A.Db;            // concat_k: column j belongs to slot j / Db
@@ -65,7 +114,7 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
     const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
     const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
     const bool scale_t = A.scale_tok != nullptr, scale_b = A.scale_byte != nullptr;
-    T *orow = (T *)A.out + (row * A.T + t0) * (int64_t)Dm;
+    T *orow = (T *)A.out + (row * A.T + u0) * (int64_t)Dm;
     auto sumsq = [](const vec_t &v) {
         float s = 0.f;
 #pragma unroll
@@ -73,36 +122,29 @@ __global__ __launch_bounds__(kThreads) void embed_mix_kernel(const MixArgs A) {
         return s;
     };
 
-    typedef typename Elem<T>::raw raw_t;
-    for (int tb = wave * U; tb < ntok; tb += kWaves * U) {
-        raw_t ar[U][NCH], br[U][NCH], br2[DUAL ? U : 1][NCH];  // rows exactly as loaded (bf16 stays packed until it is used)
+    for (int tb = 0; tb < ntok; tb += U) {
+        raw_t br[U][NCH], br2[DUAL ? U : 1][NCH];  // rows exactly as loaded (bf16 stays packed until it is used)
         vec_t bm[U][NCH];                           // MEAN accumulates while loading
         int idr[U][NCH];
-        // ---- issue every load of the U tokens before touching any of them
+        // ---- issue every load of the U tokens before touching any of them (the first batch's token rows are already in flight)
+        if (tb > 0) request_tok_rows(tb);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int t = min(tb + u, ntok - 1);  // the tail re-reads the last token; its store is skipped
-            int tok = L.tok[t];
-            if ((uint64_t)(uint32_t)tok >= (uint64_t)A.tok_rows) {
-                if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
-                tok = 0;
-            }
-            const T *trow = tok_table + (int64_t)tok * Dm;
+            const int t = min(tb + u, ntok - 1);
 #pragma unroll
             for (int i = 0; i < NCH; ++i) {
-                ar[u][i] = Elem<T>::load_raw(trow + VEC * (act[i] ? lane + 64 * i : 0));
                 if (MODE == MOT_MIX_SUM) {
-                    const int id = L.ids[t * sv + slot[i]];
+                    const int id = W.ids[t * sv + slot[i]];
                     idr[u][i] = id;
                     br[u][i] = Elem<T>::load_raw(byte_table + (int64_t)id * A.Db + within[i]);
-                    if (dual) br2[DUAL ? u : 0][i] = Elem<T>::load_raw(byte_table + (int64_t)L.val[t * sv + slot[i]] * A.Db + within[i]);
+                    if (dual) br2[DUAL ? u : 0][i] = Elem<T>::load_raw(byte_table + (int64_t)W.ids2[t * sv + slot[i]] * A.Db + within[i]);
                 } else if (MODE == MOT_MIX_MEAN) {
                     vec_t acc = (vec_t)(0.f);
                     for (int k = 0; k < A.bpt; ++k) {  // chars.mean(dim=-2), inference.py:267
-                        const int id = L.ids[t * sv + k];
+                        const int id = W.ids[t * sv + k];
                         vec_t v = Elem<T>::loadv(byte_table + (int64_t)id * A.Db + within[i]);
                         if (dual) {
-                            const int id2 = L.val[t * sv + k];
+                            const int id2 = W.ids2[t * sv + k];
                             v += Elem<T>::loadv(byte_table + (int64_t)id2 * A.Db + within[i]);
                         }
                         if (A.norm_byte) v *= A.byte_rnorm[id];
@@ -517,17 +559,28 @@ static int mean_lds_slice(const MotEmbedMixDesc &d) {
     return chunk;   // one chunk per slice: the most slices, the smallest table image
 }
 
+// Tokens per wave.  16 below 131 072 tokens: the shard a GPU gets when config 4 is split over 8 GPUs is 65 536 tokens, and 16 puts
+// 16 waves on every CU there (measured 58.8 us = 86 % of the roofline, 60.4 us with 32); 32 from there on: the index pass over
+// the 64-token window is then shared by twice the tokens (434.6 us at 524 288 tokens against 438.3).
+static int pick_unit(int64_t n_tokens) { return n_tokens >= 131072 ? 32 : 16; }
+
 int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream) {
     MixArgs A;
     fill_mix_args(A, d);
 
-    const int bpt_lds = d.mode == MOT_MIX_NOOP ? 1 : d.bpt;
-    A.tile_tokens = pick_tile_tokens(d.n_rows, d.tokens_per_row, bpt_lds, true);
-    const int64_t tiles_per_row = (d.tokens_per_row + A.tile_tokens - 1) / A.tile_tokens;
-    A.tiles_per_row = (int)tiles_per_row;
-    const int64_t blocks = d.n_rows * tiles_per_row;
-    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix: too many tiles");
-    const size_t lds = tile_lds_bytes(A.tile_tokens, bpt_lds, true);
+    const bool has_ids = d.mode != MOT_MIX_NOOP;
+    const bool dual = has_ids && (d.id_source == MOT_IDS_FROM_TTB ? d.add_padded != 0 : d.ids_b != nullptr);
+    A.unit = pick_unit(d.n_rows * d.tokens_per_row);
+#ifdef MOT_DEV_ABLATION
+    if (getenv("MOT_UNIT") && atoi(getenv("MOT_UNIT")) > 0) A.unit = atoi(getenv("MOT_UNIT"));
+#endif
+    A.units_per_row = (d.tokens_per_row + A.unit - 1) / A.unit;
+    A.n_units = d.n_rows * A.units_per_row;
+    const int64_t blocks = (A.n_units + kWaves - 1) / kWaves;
+    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix: too many units");
+    const int stream_eb = (has_ids && d.id_source == MOT_IDS_FROM_TTB && d.pull_dir != MOT_PULL_NONE) ? d.ttb_elem_bytes : 0;
+    A.wave_lds = (int)wave_lds_bytes(A.unit, has_ids ? d.bpt : 0, dual, stream_eb);
+    const size_t lds = (size_t)A.wave_lds * kWaves;
 
     if (d.mode != MOT_MIX_NOOP && d.norm_byte) {
         const size_t need = (size_t)d.byte_rows * sizeof(float);

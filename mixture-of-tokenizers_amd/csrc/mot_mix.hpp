@@ -70,7 +70,9 @@ struct MixArgs {
     float *out;
     int64_t *out_ids_padded, *out_ids_pulled, *counters;
     uint32_t *status;
-    int tile_tokens, tiles_per_row;
+    int tile_tokens, tiles_per_row;   // tile kernels (mot_linear.hip)
+    int unit, wave_lds;               // wave kernels (mot_embed.hip): tokens per wave, LDS bytes per wave
+    int64_t units_per_row, n_units;
 };
 
 constexpr float kBf16Eps = 0.0078125f;  // torch.finfo(torch.bfloat16).eps: what F.rms_norm(eps=None) uses on bf16 input

@@ -13,7 +13,8 @@ from mixture_of_tokenizers_amd import data_creation as dc
 
 dev = torch.device("cuda", 0)
 res = {}
-for rows in (32, 64, 128, 256):
+only = [int(a) for a in sys.argv[1:]] or (32, 64, 128, 256)
+for rows in only:
     inp = bench.make_inputs("c4", dev, 12345, False, rows=rows)
     T, D, bpt = 2048, 768, 16
     toks, tab = torch.from_numpy(inp["toks"]).to(dev), torch.from_numpy(inp["tab"]).to(dev)
