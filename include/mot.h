@@ -340,6 +340,53 @@ size_t mot_cross_attn_desc_size(void);
 size_t mot_cross_attn_workspace_bytes(const MotCrossAttnDesc *desc /* host */);
 int mot_cross_attn_fwd(const MotCrossAttnDesc *desc /* host */, mot_stream_t stream);
 
+/*
+ * Sliding-window token <- character attention of the Llama character mixer, forward: replaces
+ *   TokenMixByCharBMM.forward                      inference/inference.py:146-224  (swa_transform 174-179)
+ *   the residuals of TokenMixByCharBMMBlock.forward                       :260-267 (the SwiGLU feed-forward after them, 269, is
+ *   a plain MLP and stays with the caller) on top of the gathers of CustomLlamaModel.forward, :323-327.
+ * Per token t of row-major (B, T):  xn = RMSNorm_a(E_tok[t]), cn = RMSNorm_c(E_char[c]) (x * rsqrt(mean(x^2) + norm_eps) * weight,
+ * lines 126-132), q = wq xn, keys / values = wk cn / wv cn of the c_v characters of each of the tokens t-window+1 .. t of the
+ * token's batch row (zero vectors in front of the row: they keep their place in the softmax with score 0), rotary embedding of
+ * q and of every key at the query's position (see mot_swa.hip: it cancels), p = softmax(q . k / sqrt(head_dim)), y = sum p v,
+ * out = wo y  (+ toks  |  + lambda_tok toks + lambda_char mean_c chars).   fp32; head_dim 64 or 128; window * c_v <= 64.
+ * The reference cannot be imported offline (hub login at import): PARITY UNPINNED, checked against a hand-written float64 restatement.
+ */
+typedef enum MotSwaVersion { MOT_SWA_NO_RESIDUAL = 0, MOT_SWA_ONE_RESIDUAL = 1, MOT_SWA_TWO_RESIDUAL = 2 } MotSwaVersion;
+
+typedef struct MotCharSwaDesc {
+    uint32_t struct_size;       /* sizeof(MotCharSwaDesc) */
+    int32_t dtype;              /* MOT_F32 */
+    int64_t n_rows;             /* B */
+    int64_t tokens_per_row;     /* T */
+    int32_t c_v;                /* characters per token (max_char, 8) */
+    int32_t window;             /* TokenMixByCharBMM.window_size (8) */
+    int32_t n_heads, head_dim;  /* ModelArgs.n_heads, head_dim (32 x 64 for Llama-3.2-1B) */
+    int32_t dim;                /* ModelArgs.dim: columns of both tables and of out */
+    int32_t version;            /* MotSwaVersion */
+    const int32_t *tokens;      /* [B, T] */
+    const int64_t *char_ids;    /* [B, T, c_v] */
+    const void *tok_table;      /* [tok_rows, dim]  model.embed_tokens.weight */
+    int64_t tok_rows;
+    const void *char_table;     /* [char_rows, dim] char_embeddings.weight */
+    int32_t char_rows;          /* 132 */
+    float norm_eps;             /* <= 0 -> 1e-5 (ModelArgs.norm_eps) */
+    const void *attn_norm_w;    /* [dim] attention_norm.weight */
+    const void *char_norm_w;    /* [dim] char_norm.weight */
+    const void *wq, *wk, *wv;   /* [n_heads * head_dim, dim] nn.Linear weights, no bias */
+    const void *wo;             /* [dim, n_heads * head_dim] */
+    const float *lambda_tok;    /* device scalars (two_residual); NULL = 1 */
+    const float *lambda_char;
+    void *out;                  /* [B, T, dim] */
+    uint32_t *status;           /* optional, as in MotEmbedMixDesc */
+    void *workspace;            /* mot_char_swa_workspace_bytes(desc) */
+    size_t workspace_bytes;
+} MotCharSwaDesc;
+
+size_t mot_char_swa_desc_size(void);
+size_t mot_char_swa_workspace_bytes(const MotCharSwaDesc *desc /* host */);
+int mot_char_swa_fwd(const MotCharSwaDesc *desc /* host */, mot_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,7 +41,9 @@ EXPORTS = (
     "mot_embed_mix_fwd", "mot_embed_mix_bwd_workspace_bytes", "mot_embed_mix_bwd",
     "mot_cross_attn_desc_size", "mot_cross_attn_workspace_bytes", "mot_cross_attn_fwd",
     "mot_cross_attn_bwd_workspace_bytes", "mot_cross_attn_bwd",
+    "mot_char_swa_desc_size", "mot_char_swa_workspace_bytes", "mot_char_swa_fwd",
 )
+SWA_NO_RESIDUAL, SWA_ONE_RESIDUAL, SWA_TWO_RESIDUAL = 0, 1, 2
 
 
 class MotEmbedMixDesc(C.Structure):
@@ -98,6 +100,19 @@ class MotCrossAttnGrads(C.Structure):
     ]
 
 
+class MotCharSwaDesc(C.Structure):
+    """Mirror of struct MotCharSwaDesc (include/mot.h)."""
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("dtype", C.c_int32), ("n_rows", C.c_int64), ("tokens_per_row", C.c_int64),
+        ("c_v", C.c_int32), ("window", C.c_int32), ("n_heads", C.c_int32), ("head_dim", C.c_int32), ("dim", C.c_int32), ("version", C.c_int32),
+        ("tokens", C.c_void_p), ("char_ids", C.c_void_p), ("tok_table", C.c_void_p), ("tok_rows", C.c_int64),
+        ("char_table", C.c_void_p), ("char_rows", C.c_int32), ("norm_eps", C.c_float),
+        ("attn_norm_w", C.c_void_p), ("char_norm_w", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p), ("wo", C.c_void_p),
+        ("lambda_tok", C.c_void_p), ("lambda_char", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 def _load() -> C.CDLL:
     if not LIB_PATH.exists():
         raise ImportError(
@@ -129,6 +144,11 @@ def _load() -> C.CDLL:
     lib.mot_cross_attn_bwd_workspace_bytes.argtypes = [C.POINTER(MotCrossAttnDesc)]
     lib.mot_cross_attn_bwd.argtypes = [C.POINTER(MotCrossAttnDesc), C.POINTER(MotCrossAttnGrads), vp]
     lib.mot_cross_attn_bwd.restype = C.c_int
+    lib.mot_char_swa_desc_size.restype = C.c_size_t
+    lib.mot_char_swa_workspace_bytes.restype = C.c_size_t
+    lib.mot_char_swa_workspace_bytes.argtypes = [C.POINTER(MotCharSwaDesc)]
+    lib.mot_char_swa_fwd.argtypes = [C.POINTER(MotCharSwaDesc), vp]
+    lib.mot_char_swa_fwd.restype = C.c_int
     for name in ("mot_tokens_to_bytes", "mot_pull_bytes", "mot_create_batch", "mot_char_matrix", "mot_gather_rows", "mot_embed_mix_fwd",
                  "mot_embed_mix_bwd"):
         getattr(lib, name).restype = C.c_int
@@ -136,6 +156,8 @@ def _load() -> C.CDLL:
         raise ImportError(f"libmot_hip.so ABI {lib.mot_version()} != binding ABI {ABI_VERSION}")
     if lib.mot_embed_mix_desc_size() != C.sizeof(MotEmbedMixDesc):
         raise ImportError("MotEmbedMixDesc layout mismatch between include/mot.h and _capi.py")
+    if lib.mot_char_swa_desc_size() != C.sizeof(MotCharSwaDesc):
+        raise ImportError("MotCharSwaDesc layout mismatch between include/mot.h and _capi.py")
     if lib.mot_cross_attn_desc_size() != C.sizeof(MotCrossAttnDesc):
         raise ImportError("MotCrossAttnDesc layout mismatch between include/mot.h and _capi.py")
     return lib

@@ -31,6 +31,17 @@
 
 namespace mot {
 
+// Ordering of one wave's traffic on its per-slot LDS accumulators (seg / segr / seg_q): a plain zeroing store by every lane,
+// LDS atomics from other lanes, a plain read-back.  DS instructions of one wave execute in issue order; what has to be pinned is
+// the COMPILER's order across lanes: a release fence, a wave barrier (lanes are separate threads to the memory model: the
+// barrier is what orders lane A's store before lane B's atomic) and an acquire fence.  No instruction beyond the waits the
+// fences imply.
+__device__ __forceinline__ void seg_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 constexpr int kBwdThreads = 512;  // 8 waves, 2 per SIMD: a 256-register budget per lane
 constexpr int kBwdWaves = kBwdThreads / 64;
 constexpr int kWindow = 64;  // sorted positions per wave work item
@@ -196,15 +207,15 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
             // norm(emb(padded) + emb(pulled)) (train_gpt.py:378): the rms factor belongs to the (token, slot) pair,
             // not to a table row -- reduce sum(b^2) per slot through the wave's LDS accumulators
             segr[lane] = 0.f;   // all 64 lanes (kMaxBpt entries): a `lane < bpt` guard lets the compiler reorder the adds around it
-            __threadfence_block();
+            seg_sync();
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int eb = byte_off(lane + 64 * j);
                 if (eb >= 0) atomicAdd(&segr[slot_of(eb)], bn[j] * bn[j]);
             }
-            __threadfence_block();
+            seg_sync();
             segr[lane] = rms_scale(segr[lane], A.Db, A.eps);
-            __threadfence_block();
+            seg_sync();
 #pragma unroll
             for (int j = 0; j < NE; ++j) {
                 const int eb = byte_off(lane + 64 * j);
@@ -263,13 +274,13 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
             ds_b += dot;
             if (A.norm_byte) {  // per-slot mean(db * b_n): slots are ragged lane groups -> LDS accumulators
                 seg[lane] = 0.f;
-                __threadfence_block();
+                seg_sync();
 #pragma unroll
                 for (int j = 0; j < NE; ++j) {
                     const int eb = byte_off(lane + 64 * j);
                     if (eb >= 0) atomicAdd(&seg[slot_of(eb)], dy[j] * s_byte * bn[j]);
                 }
-                __threadfence_block();
+                seg_sync();
             }
             float vmax = 0.f;
 #pragma unroll
@@ -303,7 +314,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
                     add_byte((int)ib, wi, dy[j]);
                 }
             }
-            if (A.norm_byte) __threadfence_block();  // seg is rewritten by the next token
+            if (A.norm_byte) seg_sync();  // seg is rewritten by the next token
         }
     }
     }
@@ -626,13 +637,13 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     pmax = wave_max(pmax);
                     const int kk = (pmax > 0.f && pmax < INFINITY) ? 40 - ilogbf(pmax) : 0;
                     seg_q[lane] = 0ull;
-                    __threadfence_block();
+                    seg_sync();
 #pragma unroll
                     for (int j = 0; j < NE; ++j)
                         if (bmask >> j & 1) atomicAdd(seg_q + (sl4[j] >> 2), to_fixed(bn[j] * bn[j], kk));
-                    __threadfence_block();
+                    seg_sync();
                     rnb = rms_scale((float)ldexp((double)(long long)seg_q[lane], -kk), A.Db, A.eps);
-                    __threadfence_block();
+                    seg_sync();
                 } else {
                     rnb = A.byte_rnorm[ida];
                 }
@@ -686,11 +697,11 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                     // `lane < bpt` guard the compiler sinks the atomics into both sides of the branch and the
                     // unguarded lanes' adds run BEFORE the zeroing store
                     seg_q[lane] = 0ull;
-                    __threadfence_block();
+                    seg_sync();
 #pragma unroll
                     for (int j = 0; j < NE; ++j)
                         if (bmask >> j & 1) atomicAdd(seg_q + (sl4[j] >> 2), to_fixed(dy[j] * bn[j], kk));
-                    __threadfence_block();
+                    seg_sync();
                     float sg = (float)ldexp((double)(long long)seg_q[lane], -kk) / (float)A.Db;
                     if (!(pmax < INFINITY)) sg = NAN;   // non-finite gradients stay non-finite
 #pragma unroll
@@ -699,7 +710,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
                         const float sj = __int_as_float(__builtin_amdgcn_ds_bpermute(sl4[j], __float_as_int(sg)));
                         dy[j] = rj * (dy[j] - bn[j] * sj);
                     }
-                    __threadfence_block();
+                    seg_sync();
                 }
                 if (!(A.abl & 1)) {
                     bool slow = false;   // some element of this lane needs the exact path
@@ -1344,7 +1355,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 4))
 // (the reduction can be cut into launches that add to C; with the in-kernel blocked summation one launch covers any K)
 constexpr int kGemmRowsPass = 1 << 30;
 int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed,
-                     hipStream_t stream, const float *bias) {
+                     hipStream_t stream, const float *bias, bool accumulate) {
     if (n <= 0 || Nc <= 0) return MOT_OK;
     const int64_t gx = (n + 127) / 128;
     const int gy = (Nc + 127) / 128;
@@ -1355,10 +1366,10 @@ int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int l
         const float *a = A_ + r0, *b = b_transposed ? B_ + r0 : B_ + (int64_t)r0 * ldb;
         if (b_transposed)
             hipLaunchKernelGGL(gemm_rows_bt_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
-                               r0 ? nullptr : bias, r0 ? 1 : 0);
+                               r0 ? nullptr : bias, (r0 || accumulate) ? 1 : 0);
         else
             hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
-                               r0 ? nullptr : bias, r0 ? 1 : 0);
+                               r0 ? nullptr : bias, (r0 || accumulate) ? 1 : 0);
         if (r0 + kGemmRowsPass >= R) break;
     }
     return check_launch("gemm_rows_kernel");

@@ -213,6 +213,40 @@ int mot_embed_mix_fwd(const MotEmbedMixDesc *desc, mot_stream_t stream) {
     return launch_embed_mix(*desc, (hipStream_t)stream);
 }
 
+size_t mot_char_swa_desc_size(void) { return sizeof(MotCharSwaDesc); }
+
+static int validate_char_swa(const MotCharSwaDesc *d) {
+    if (!d) return set_error(MOT_EINVAL, "char_swa: null descriptor");
+    if (d->struct_size != sizeof(MotCharSwaDesc))
+        return set_error(MOT_EINVAL, "char_swa: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(MotCharSwaDesc));
+    if (d->dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "char_swa: only MOT_F32 is built");
+    if (d->n_rows < 0 || d->tokens_per_row < 0) return set_error(MOT_ESHAPE, "char_swa: negative shape");
+    if (d->c_v < 1 || d->window < 1 || d->c_v * d->window > 64)
+        return set_error(MOT_EUNSUPPORTED, "char_swa: window %d x %d characters must give 1..64 keys per query", d->window, d->c_v);
+    if (d->head_dim != 64 && d->head_dim != 128) return set_error(MOT_EUNSUPPORTED, "char_swa: head_dim %d (64 and 128 are built)", d->head_dim);
+    if (d->n_heads < 1 || d->dim < 4 || (d->dim & 3)) return set_error(MOT_ESHAPE, "char_swa: n_heads %d / dim %d (dim must be a multiple of 4)", d->n_heads, d->dim);
+    if (d->version < MOT_SWA_NO_RESIDUAL || d->version > MOT_SWA_TWO_RESIDUAL) return set_error(MOT_EINVAL, "char_swa: bad version %d", d->version);
+    if (!d->tokens || !d->char_ids || !d->tok_table || !d->char_table || !d->attn_norm_w || !d->char_norm_w || !d->wq || !d->wk || !d->wv || !d->wo || !d->out)
+        return set_error(MOT_EINVAL, "char_swa: tokens/char_ids/tables/norm weights/projections/out must be non-null");
+    if (d->tok_rows <= 0 || d->char_rows <= 0) return set_error(MOT_ESHAPE, "char_swa: empty table");
+    if (d->version == MOT_SWA_TWO_RESIDUAL && d->dim > 2048) return set_error(MOT_EUNSUPPORTED, "char_swa: the two_residual mean needs dim <= 2048");
+    return MOT_OK;
+}
+
+size_t mot_char_swa_workspace_bytes(const MotCharSwaDesc *desc) {
+    if (!desc || desc->struct_size != sizeof(MotCharSwaDesc) || desc->n_heads < 1 || desc->head_dim < 1 || desc->dim < 1 || desc->char_rows < 1 ||
+        desc->n_rows < 0 || desc->tokens_per_row < 0)
+        return 0;
+    return char_swa_workspace_bytes(*desc);
+}
+
+int mot_char_swa_fwd(const MotCharSwaDesc *desc, mot_stream_t stream) {
+    int rc = validate_char_swa(desc);
+    if (rc) return rc;
+    if (desc->n_rows == 0 || desc->tokens_per_row == 0) return MOT_OK;
+    return launch_char_swa(*desc, (hipStream_t)stream);
+}
+
 size_t mot_cross_attn_desc_size(void) { return sizeof(MotCrossAttnDesc); }
 
 static int validate_cross_attn(const MotCrossAttnDesc *d) {

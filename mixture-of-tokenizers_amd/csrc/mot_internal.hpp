@@ -54,7 +54,7 @@ int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &g, hi
 int launch_gemm_tn(const float *A, int lda, int M, const float *B, int ldb, int Nc, int64_t n, float *C, int ldc, hipStream_t stream);
 // C[n][c] = sum_r A[n][r] * (b_transposed ? B[c][r] : B[r][c]) (+ bias[c]), fp32 MFMA, plain stores
 int launch_gemm_rows(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed, hipStream_t stream,
-                     const float *bias = nullptr);
+                     const float *bias = nullptr, bool accumulate = false);
 // the composed concat + linear forward (index kernels, seam gather, dense MFMA kernel, row norm), fp32 and bf16 (mot_linear.hip)
 bool embed_mix_linear_is_composed(const MotEmbedMixDesc &d);
 size_t embed_mix_linear_composed_workspace_bytes(const MotEmbedMixDesc &d);
@@ -71,6 +71,8 @@ int launch_group_positions(const int32_t *ids, int64_t n, int64_t rows, int32_t 
 int launch_zero_words(void *p, int64_t n_words, hipStream_t stream);
 size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d);
 int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &g, hipStream_t stream);
+size_t char_swa_workspace_bytes(const MotCharSwaDesc &d);
+int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream);
 size_t cross_attn_workspace_bytes(const MotCrossAttnDesc &d);
 int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream);
 

@@ -1,0 +1,217 @@
+// mot_swa.hip -- the Llama character mixer of BASELINE config 5 (gfx950): sliding-window token <- character attention
+// (inference/inference.py:146-224, TokenMixByCharBMM) on top of the two embedding gathers (323-327), with the residuals of
+// TokenMixByCharBMMBlock.forward (260-267).  fp32.
+//
+//   xn = RMSNorm_a(E_tok[t])                 attention_norm, eps = norm_eps, learned weight           (lines 126-132, 261-267)
+//   cn = RMSNorm_c(E_char[c])                char_norm
+//   q  = wq xn;   k = wk cn;   v = wv cn     per token / per character embedding                     (199-200)
+//   keys of token t = the c_v characters of each of the tokens t-7 .. t of its batch row, zero vectors in front of the row
+//                                            swa_transform: key j = w * c_v + c, w = 0 the oldest    (174-179)
+//   RoPE over the first head_dim / 2 elements of q AND of every key, at the QUERY's position t        (209-217)
+//   p  = softmax_j(q . k_j / sqrt(head_dim));   y = sum_j p_j v_j;   out = wo y                       (219-238)
+//   h  = out (+ lambda_tok E_tok[t] + lambda_char mean_c E_char[c])                                   (260-267)
+//
+// What the kernels exploit:
+//   * k and v depend on the CHARACTER ID only (132 ids): they are projected once per character-table row into two
+//     L2-resident tables [132, n_heads * head_dim] instead of once per (token, slot) -- 500 x fewer flops at 65 536 tokens;
+//   * q and every key of a query are rotated by the same angle (both sit at position t in the reference's layout, lines
+//     209-217), and a rotation applied to both factors leaves q . k unchanged: the rotation is skipped.  The float64
+//     checker of the parity tests does rotate, per the published algorithm of rotary-embedding-torch, so the tests check
+//     exactly this identity (to fp32 rounding);
+//   * zero-padded keys keep their place in the softmax (score 0, value 0), as in the reference.
+#include <string.h>
+
+#include "mot_mix.hpp"
+
+namespace mot {
+
+// out[n] = weight * (x * rsqrt(mean(x^2) + eps)), x = table[ids ? ids[n] : n]   (RMSNorm.forward, inference.py:126-132).
+// One wave per row, 16-byte lanes.
+template <typename IdT>
+__global__ __launch_bounds__(kThreads) void rows_rmsnorm_w_kernel(const IdT *__restrict__ ids, int64_t n, const float *__restrict__ table, int64_t rows,
+                                                                  int dim, const float *__restrict__ weight, float eps, float *__restrict__ out,
+                                                                  uint32_t *status, uint32_t oor_flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (r >= n) return;
+    int64_t id = ids ? (int64_t)ids[r] : r;
+    if ((uint64_t)id >= (uint64_t)rows) {
+        if (status && lane == 0) atomicOr(status, oor_flag);
+        id = 0;
+    }
+    const float *p = table + id * dim;
+    float *o = out + r * dim;
+    const int nv = dim >> 2;
+    float ss = 0.f;
+    for (int j = lane; j < nv; j += 64) {
+        const float4v v = *(const float4v *)(p + 4 * j);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float rs = 1.0f / sqrtf(ss / (float)dim + eps);       // torch.rsqrt(x.pow(2).mean(-1) + eps), correctly rounded pieces
+    for (int j = lane; j < nv; j += 64) {
+        const float4v v = *(const float4v *)(p + 4 * j), w = *(const float4v *)(weight + 4 * j);
+        *(float4v *)(o + 4 * j) = (v * rs) * w;
+    }
+}
+
+// The attention core.  Workgroup = (head h, tile of TT tokens); K_h and V_h of all character rows live in LDS for the whole
+// tile (132 x 64 x 2 floats = 68 KB at head_dim 64: two workgroups per CU); one wave per token.
+//   scores: lane = key (window * c_v <= 64 of them): 64 fmas of the lane's key row (LDS, padded rows) with q handed out lane by lane
+//   softmax: two wave reductions
+//   y:      lane = element of the head (HD / 64 per lane): a loop over the keys, p and the key's character id handed out by readlane
+template <int HDL>   // head_dim = 64 * HDL
+__global__ __launch_bounds__(kThreads) void char_swa_kernel(const float *__restrict__ q, const float *__restrict__ ktab, const float *__restrict__ vtab,
+                                                            const int64_t *__restrict__ char_ids, int64_t n0, int64_t n_tok, int64_t T, int c_v, int window,
+                                                            int char_rows, int n_heads, int tile_tokens, float *__restrict__ y, uint32_t *status) {
+    constexpr int HD = 64 * HDL, KS = HD + 4;                    // key rows padded by 16 bytes: lanes reading different rows spread over the banks
+    extern __shared__ __attribute__((aligned(16))) float lds_kv[];
+    float *lk = lds_kv, *lv = lds_kv + (size_t)char_rows * KS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.y;
+    const int HDIM = n_heads * HD;
+    for (int i = tid; i < char_rows * (HD / 4); i += kThreads) {
+        const int r = i / (HD / 4), c = (i - r * (HD / 4)) * 4;
+        *(float4v *)(lk + r * KS + c) = *(const float4v *)(ktab + (int64_t)r * HDIM + h * HD + c);
+        *(float4v *)(lv + r * HD + c) = *(const float4v *)(vtab + (int64_t)r * HDIM + h * HD + c);
+    }
+    __syncthreads();
+    const int nkeys = window * c_v;
+    const int w = lane / c_v, c = lane - w * c_v;                 // this lane's key: window slot w (0 = oldest), character slot c
+    const float scale = 1.0f / sqrtf((float)HD);                 // qk / self.head_dim ** .5, line 220
+    const int64_t t_lo = (int64_t)blockIdx.x * tile_tokens, t_hi = min(n_tok, t_lo + tile_tokens);
+    for (int64_t tl = t_lo + wave; tl < t_hi; tl += kWaves) {
+        const int64_t n = n0 + tl;                               // flat token index; the window may not leave the token's batch row
+        const int64_t tr = n % T;
+        const int64_t src_t = tr - (window - 1) + w;
+        const bool is_key = lane < nkeys, real = is_key && src_t >= 0;   // src_t < 0: a zero vector of the padding (lines 175-176)
+        int id = 0;
+        if (real) {
+            const int64_t v = char_ids[(n - tr + src_t) * c_v + c];
+            id = (int)v;
+            if ((uint64_t)v >= (uint64_t)char_rows) { if (status) atomicOr(status, kStatusByteOor); id = 0; }
+        }
+        float qv[HDL];
+#pragma unroll
+        for (int g = 0; g < HDL; ++g) qv[g] = q[tl * HDIM + h * HD + lane + 64 * g];
+        // ---- scores
+        float s = 0.f;
+        const float *krow = lk + id * KS;
+#pragma unroll
+        for (int g = 0; g < HDL; ++g) {
+#pragma unroll
+            for (int d4 = 0; d4 < 16; ++d4) {
+                const float4v kk = *(const float4v *)(krow + 64 * g + 4 * d4);
+                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 0)) * kk.x;
+                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 1)) * kk.y;
+                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 2)) * kk.z;
+                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 3)) * kk.w;
+            }
+        }
+        s = real ? s * scale : 0.f;
+        // ---- softmax over the nkeys keys (padding keys included, score 0)
+        const float m = wave_max(is_key ? s : -INFINITY);
+        const float e = is_key ? expf(s - m) : 0.f;
+        const float p = e / wave_sum(e);
+        const float pv = real ? p : 0.f;                         // a padding key's value is the zero vector
+        // ---- y = sum_j p_j v_j, lane = element
+        float acc[HDL];
+#pragma unroll
+        for (int g = 0; g < HDL; ++g) acc[g] = 0.f;
+        for (int j = 0; j < nkeys; ++j) {
+            const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), j));
+            const int idj = __builtin_amdgcn_readlane(id, j);
+#pragma unroll
+            for (int g = 0; g < HDL; ++g) acc[g] += pj * lv[idj * HD + lane + 64 * g];
+        }
+#pragma unroll
+        for (int g = 0; g < HDL; ++g) y[tl * HDIM + h * HD + lane + 64 * g] = acc[g];
+    }
+}
+
+static size_t swa_align(size_t n) { return (n + 63) & ~(size_t)63; }
+constexpr int64_t kSwaSlab = 65536;    // tokens per pass: bounds the workspace (normalised rows, queries, attention output)
+
+size_t char_swa_workspace_bytes(const MotCharSwaDesc &d) {
+    const int64_t N = d.n_rows * d.tokens_per_row, slab = N < kSwaSlab ? N : kSwaSlab;
+    const size_t hdim = (size_t)d.n_heads * d.head_dim;
+    // [cn: char_rows x dim][K, V: char_rows x hdim each][xn | y: slab x max(dim, hdim)][q: slab x hdim][byte_rnorm scratch of the residual call]
+    const size_t fl = swa_align((size_t)d.char_rows * d.dim) + 2 * swa_align((size_t)d.char_rows * hdim) +
+                      swa_align((size_t)slab * (d.dim > (int)hdim ? d.dim : hdim)) + swa_align((size_t)slab * hdim) + swa_align(d.char_rows);
+    return fl * sizeof(float);
+}
+
+int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
+    const int64_t N = d.n_rows * d.tokens_per_row;
+    const int hdim = d.n_heads * d.head_dim;
+    const size_t need = char_swa_workspace_bytes(d);
+    if (!d.workspace || d.workspace_bytes < need) return set_error(MOT_EWORKSPACE, "char_swa: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
+    const int64_t slab = N < kSwaSlab ? N : kSwaSlab;
+    float *cn = (float *)d.workspace;
+    float *kt = cn + swa_align((size_t)d.char_rows * d.dim), *vt = kt + swa_align((size_t)d.char_rows * hdim);
+    float *xn = vt + swa_align((size_t)d.char_rows * hdim), *yb = xn;   // the attention output reuses the normalised rows' buffer
+    float *qb = xn + swa_align((size_t)slab * (d.dim > hdim ? d.dim : hdim));
+    float *rn_scratch = qb + swa_align((size_t)slab * hdim);
+    const float eps = d.norm_eps > 0.f ? d.norm_eps : 1e-5f;   // ModelArgs.norm_eps default, inference.py:43
+    int rc;
+    // ---- per character-table row: normalise, project to keys and values
+    hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int64_t>, dim3((unsigned)((d.char_rows + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream,
+                       (const int64_t *)nullptr, (int64_t)d.char_rows, (const float *)d.char_table, (int64_t)d.char_rows, d.dim,
+                       (const float *)d.char_norm_w, eps, cn, d.status, kStatusByteOor);
+    if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
+    if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wk, d.dim, d.dim, hdim, kt, hdim, true, stream))) return rc;
+    if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wv, d.dim, d.dim, hdim, vt, hdim, true, stream))) return rc;
+    const size_t lds = ((size_t)d.char_rows * (d.head_dim + 4) + (size_t)d.char_rows * d.head_dim) * sizeof(float);
+    if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "char_swa: %d character rows x head_dim %d need %zu B of LDS (> 160 KiB)", d.char_rows, d.head_dim, lds);
+    for (int64_t n0 = 0; n0 < N; n0 += slab) {
+        const int64_t nn = N - n0 < slab ? N - n0 : slab;
+        float *out = (float *)d.out + n0 * d.dim;
+        // ---- queries: gather + RMSNorm, then the projection
+        hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int32_t>, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.tokens + n0, nn,
+                           (const float *)d.tok_table, d.tok_rows, d.dim, (const float *)d.attn_norm_w, eps, xn, d.status, kStatusTokenOor);
+        if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
+        if ((rc = launch_gemm_rows(xn, d.dim, nn, (const float *)d.wq, d.dim, d.dim, hdim, qb, hdim, true, stream))) return rc;
+        // ---- attention
+        const int tile = 128;
+        const dim3 grid((unsigned)((nn + tile - 1) / tile), (unsigned)d.n_heads);
+        if (d.head_dim == 64) {
+            static std::atomic<uint64_t> lds_ok{0};
+            if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<1>, lds_ok, "char_swa_kernel"))) return rc;
+            hipLaunchKernelGGL(char_swa_kernel<1>, grid, dim3(kThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
+                               d.char_rows, d.n_heads, tile, yb, d.status);
+        } else {
+            static std::atomic<uint64_t> lds_ok{0};
+            if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<2>, lds_ok, "char_swa_kernel"))) return rc;
+            hipLaunchKernelGGL(char_swa_kernel<2>, grid, dim3(kThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
+                               d.char_rows, d.n_heads, tile, yb, d.status);
+        }
+        if ((rc = check_launch("char_swa_kernel"))) return rc;
+        // ---- residuals first (they overwrite `out`), then out += wo y
+        bool accumulate = false;
+        if (d.version != MOT_SWA_NO_RESIDUAL) {
+            MotEmbedMixDesc r;
+            memset(&r, 0, sizeof(r));
+            r.struct_size = sizeof(r);
+            r.dtype = MOT_F32;
+            r.n_rows = 1; r.tokens_per_row = nn;                  // no pull: rows are independent, a slab is one flat row
+            r.tokens = d.tokens + n0;
+            r.tok_table = d.tok_table; r.tok_rows = d.tok_rows; r.tok_dim = d.dim; r.model_dim = d.dim;
+            r.out = out; r.status = d.status;
+            if (d.version == MOT_SWA_TWO_RESIDUAL) {              // + lambda_tok * toks + lambda_char * chars.mean(dim=-2), line 267
+                r.mode = MOT_MIX_MEAN; r.bpt = d.c_v; r.id_source = MOT_IDS_GIVEN; r.ids_a = d.char_ids + n0 * d.c_v;
+                r.byte_table = d.char_table; r.byte_rows = d.char_rows; r.byte_dim = d.dim;
+                r.scale_tok = d.lambda_tok; r.scale_byte = d.lambda_char;
+                r.workspace = rn_scratch; r.workspace_bytes = (size_t)d.char_rows * sizeof(float);
+            } else {                                               // + toks, line 264
+                r.mode = MOT_MIX_NOOP;
+            }
+            if ((rc = launch_embed_mix(r, stream))) return rc;
+            accumulate = true;
+        }
+        if ((rc = launch_gemm_rows(yb, hdim, nn, (const float *)d.wo, hdim, hdim, d.dim, out, d.dim, true, stream, nullptr, accumulate))) return rc;
+    }
+    return MOT_OK;
+}
+
+}  // namespace mot

@@ -630,3 +630,56 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
     # byte table, kv_w and lambda_factor are unchanged (tensor versions are checked)
     return _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
                            kv_cache=kv_cache, **kw)
+
+
+_SWA_VERSIONS = {"no_residual": capi.SWA_NO_RESIDUAL, "one_residual": capi.SWA_ONE_RESIDUAL, "two_residual": capi.SWA_TWO_RESIDUAL}
+
+
+@torch.compiler.disable
+def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tensor, char_table: torch.Tensor, *,
+             attn_norm_w: torch.Tensor, char_norm_w: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, wo: torch.Tensor,
+             n_heads: int, head_dim: int, window: int = 8, norm_eps: float = 1e-5, version: str = "two_residual",
+             lambda_tok: torch.Tensor | None = None, lambda_char: torch.Tensor | None = None) -> torch.Tensor:
+    """The Llama character mixer up to the feed-forward (inference.py:146-224 + 260-267 on the gathers of 323-327):
+    tokens (B, T) int, char_ids (B, T, c_v) int64 -> h (B, T, dim) fp32.  Forward only (the file is the reference's inference
+    path); see mot_char_swa_fwd in include/mot.h."""
+    if tokens.ndim == 1:
+        tokens, char_ids = tokens[None], char_ids[None]
+    if char_ids.ndim != 3 or char_ids.shape[:2] != tokens.shape:
+        raise ValueError(f"char_ids must be (B, T, c_v) matching tokens {tuple(tokens.shape)}, got {tuple(char_ids.shape)}")
+    params = (tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, lambda_tok, lambda_char)
+    if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
+        raise RuntimeError("mixture-of-tokenizers_amd: the character mixer (inference/inference.py) is built forward-only; call it under "
+                           "torch.no_grad() or with frozen parameters")
+    dev = capi.require_device(tokens, char_ids, *params)
+    f32 = torch.float32
+    tok = _contig(tokens.to(torch.int32), torch.int32, "tokens")
+    cid = _contig(char_ids, torch.int64, "char_ids")
+    B, T = tok.shape
+    tt, ct = _contig(tok_table.detach(), f32, "tok_table"), _contig(char_table.detach(), f32, "char_table")
+    D, hdim = tt.shape[1], n_heads * head_dim
+    if ct.shape[1] != D:
+        raise ValueError("char_table and tok_table must have the same number of columns (hidden_size)")
+    ws_ = [_contig(w.detach(), f32, n) for w, n in ((attn_norm_w, "attn_norm_w"), (char_norm_w, "char_norm_w"), (wq, "wq"), (wk, "wk"), (wv, "wv"), (wo, "wo"))]
+    if ws_[0].shape != (D,) or ws_[1].shape != (D,) or any(w.shape != (hdim, D) for w in ws_[2:5]) or ws_[5].shape != (D, hdim):
+        raise ValueError(f"char_swa: weight shapes do not fit dim {D}, heads {n_heads} x {head_dim}")
+    lams = [None if l is None else _contig(l.detach().reshape(1), f32, "lambda") for l in (lambda_tok, lambda_char)]
+    d = capi.MotCharSwaDesc()
+    d.struct_size = C.sizeof(capi.MotCharSwaDesc)
+    d.dtype, d.n_rows, d.tokens_per_row = capi.F32, B, T
+    d.c_v, d.window, d.n_heads, d.head_dim, d.dim = cid.shape[2], int(window), int(n_heads), int(head_dim), D
+    d.version = _SWA_VERSIONS[version]
+    d.tokens, d.char_ids = capi.ptr(tok), capi.ptr(cid)
+    d.tok_table, d.tok_rows, d.char_table, d.char_rows = capi.ptr(tt), tt.shape[0], capi.ptr(ct), ct.shape[0]
+    d.norm_eps = float(norm_eps)
+    d.attn_norm_w, d.char_norm_w, d.wq, d.wk, d.wv, d.wo = (capi.ptr(w) for w in ws_)
+    d.lambda_tok, d.lambda_char = capi.ptr(lams[0]), capi.ptr(lams[1])
+    out = torch.empty((B, T, D), dtype=f32, device=dev)
+    d.out = capi.ptr(out)
+    d.status = capi.ptr(capi.status_word(dev))
+    ws = _workspace(dev, capi.lib.mot_char_swa_workspace_bytes(C.byref(d)))
+    if ws is not None:
+        d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
+    capi.check(capi.lib.mot_char_swa_fwd(C.byref(d), capi.stream_of(dev)))
+    capi.after_call(dev)
+    return out

@@ -533,3 +533,120 @@ class SumFrontEnd(nn.Module):
             kw.update(ids_a=byte_inputs.to(torch.int64).reshape(1 if token_inputs.ndim == 1 else token_inputs.shape[0], -1))
         return F_mot.embed_mix(token_inputs, _f32(self.embed_tokens.weight, "token table"),
                                _f32(self.embed_bytes.weight, "byte table"), mode="sum", bpt=self.bpt, **kw)
+
+
+# ------------------------------------------------------------------------------------------------
+# Llama character mixer (inference/inference.py): BASELINE config 5's front-end
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ModelArgs:  # inference.py:36-43
+    version: Literal["no_residual", "one_residual", "two_residual"]
+    n_heads: int = 32
+    dim: int = 2048
+    intermediate_dim: int = 8192
+    head_dim: int = 64
+    norm_eps: float = 1e-5
+
+
+class RMSNorm(nn.Module):  # inference.py:119-132 (a plain torch module: the trunk uses it on arbitrary activations)
+    def __init__(self, dim: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+
+    def _norm(self, x):
+        return x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + self.eps)
+
+    def forward(self, x):
+        return self._norm(x.float()).type_as(x) * self.weight
+
+
+class FeedForward(nn.Module):  # inference.py:135-144, SwiGLU: plain dense layers, outside the embedding path (torch ops)
+    def __init__(self, args: ModelArgs):
+        super().__init__()
+        self.w1 = nn.Linear(args.dim, args.intermediate_dim, bias=False)
+        self.w2 = nn.Linear(args.intermediate_dim, args.dim, bias=False)
+        self.w3 = nn.Linear(args.dim, args.intermediate_dim, bias=False)
+
+    def forward(self, x) -> Tensor:
+        return self.w2(F.silu(self.w1(x)) * self.w3(x))
+
+
+class TokenMixByCharBMM(nn.Module):
+    """inference.py:146-224: the parameters (wq, wk, wv, wo; window_size 8) under the reference's names.  The work itself
+    -- including the two RMSNorms in front and the residuals behind, which the reference's block applies around this module --
+    runs in ONE library call issued by TokenMixByCharBMMBlock.forward; this class only holds the weights."""
+
+    def __init__(self, args: ModelArgs):
+        super().__init__()
+        self.args = args
+        self.n_heads, self.head_dim = args.n_heads, args.head_dim
+        self.bmm_dim = args.n_heads * args.head_dim
+        self.wq = nn.Linear(args.dim, self.bmm_dim, bias=False)
+        self.wk = nn.Linear(args.dim, self.bmm_dim, bias=False)
+        self.wv = nn.Linear(args.dim, self.bmm_dim, bias=False)
+        self.wo = nn.Linear(self.bmm_dim, args.dim, bias=False)
+        self.attention_scores = None      # the reference keeps the last softmax here (line 225); the fused kernel does not materialise it
+        self.window_size = 8
+
+
+class TokenMixByCharBMMBlock(nn.Module):
+    """inference.py:226-270 with the same parameters and state-dict keys.  ``forward(toks, chars, rotary_emb_fn=None)`` takes
+    the EmbedHandles of the two embeddings (CharMixerFrontEnd below / LazyEmbedding) instead of materialised (b, t, d) and
+    (b, t, c_v, d) tensors: keys and values are projected once per character-table ROW, which needs the ids.
+    ``rotary_emb_fn`` is accepted and unused: the reference rotates the query and each of its keys by the same angle (both sit
+    at the query's position, lines 209-217), which leaves their product unchanged (mot_swa.hip).  Forward only."""
+
+    def __init__(self, args: ModelArgs):
+        super().__init__()
+        self.n_heads, self.dim = args.n_heads, args.dim
+        self.tok_attention = TokenMixByCharBMM(args)
+        self.feed_forward = FeedForward(args=args)
+        self.attention_norm = RMSNorm(args.dim, eps=args.norm_eps)
+        self.char_norm = RMSNorm(args.dim, eps=args.norm_eps)
+        self.ffn_norm = RMSNorm(args.dim, eps=args.norm_eps)
+        self.args, self.version = args, args.version
+        if self.version in ["two_residual", "no_residual"]:
+            self.lambda_tok = nn.Parameter(torch.ones(1))
+            self.lambda_char = nn.Parameter(torch.ones(1))
+        if self.version == "two_residual":
+            self.register_buffer("current_step", torch.tensor(0))
+
+    def get_residual_scale(self):  # inference.py:247-250
+        return min(self.current_step.item() / 5000, 1.0)
+
+    def mix(self, toks: EmbedHandle, chars: EmbedHandle) -> Tensor:
+        """``h`` of the reference's forward (lines 260-267): attention + residuals, before the feed-forward."""
+        if not (isinstance(toks, EmbedHandle) and isinstance(chars, EmbedHandle)):
+            raise NotImplementedError("TokenMixByCharBMMBlock: pass the embedding handles (token ids + table, character ids + table); "
+                                      "materialised embeddings are not built")
+        ta = self.tok_attention
+        tokens, cid = toks.tokens, chars.ids_a
+        if tokens.ndim == 1:
+            tokens, cid = tokens[None], cid[None]
+        cid = cid.reshape(tokens.shape[0], tokens.shape[1], -1)
+        two = self.version == "two_residual"
+        return F_mot.char_swa(tokens, cid, toks.tok_weight, chars.byte_weight, attn_norm_w=self.attention_norm.weight,
+                              char_norm_w=self.char_norm.weight, wq=ta.wq.weight, wk=ta.wk.weight, wv=ta.wv.weight, wo=ta.wo.weight,
+                              n_heads=ta.n_heads, head_dim=ta.head_dim, window=ta.window_size, norm_eps=self.attention_norm.eps,
+                              version=self.version, lambda_tok=self.lambda_tok if two else None, lambda_char=self.lambda_char if two else None)
+
+    def forward(self, toks, chars, rotary_emb_fn=None) -> Tensor:
+        h = self.mix(toks, chars)
+        return h + self.feed_forward.forward(self.ffn_norm(h))          # line 269: plain torch
+
+
+class CharMixerFrontEnd(nn.Module):
+    """The embedding front of CustomLlamaModel (inference.py:273-335): ``embed_tokens`` (the Llama table), ``char_embeddings``
+    (132 rows) and ``char_token_mixer``, and the first lines of its forward (323-335) -> ``mixed_embeddings`` for the trunk.
+    The pretrained trunk itself (``self.model``) is out of scope; adopt its ``embed_tokens.weight`` into this table."""
+
+    def __init__(self, vocab_size: int, char_vocab_size: int, model_args: ModelArgs, max_char: int = 8):
+        super().__init__()
+        self.embed_tokens = LazyEmbedding(vocab_size, model_args.dim, "tokens")
+        self.char_embeddings = LazyEmbedding(char_vocab_size, model_args.dim, "bytes", max_char)
+        self.max_char = max_char
+        self.char_token_mixer = TokenMixByCharBMMBlock(model_args)
+
+    def forward(self, input_ids: Tensor, char_ids: Tensor) -> Tensor:
+        return self.char_token_mixer(self.embed_tokens(input_ids), self.char_embeddings(char_ids), None)

@@ -355,3 +355,63 @@ def create_char_matrix(char_tokens, seq_len: int, max_char: int = 8) -> np.ndarr
         if ind < max_char:
             mat[row][ind] = 130
     return mat.astype(np.int64)
+
+
+def _rotary_rotate(t: np.ndarray, rot_dim: int, theta: float = 10000.0) -> np.ndarray:
+    """rotary_embedding_torch.RotaryEmbedding(dim=rot_dim).rotate_queries_or_keys(t) with seq_dim = -2 -- a third-party
+    dependency absent from /root/reference (imported at inference.py:19, version not pinned by the reference); restated
+    from its published algorithm: freqs_f = theta ** -(2f / rot_dim), f < rot_dim / 2; angle(pos, 2f) = angle(pos, 2f+1) =
+    pos * freqs_f; the first rot_dim elements are rotated in ADJACENT pairs (x1, x2) -> (x1 cos - x2 sin, x2 cos + x1 sin),
+    the rest pass through."""
+    seq = t.shape[-2]
+    freqs = 1.0 / (theta ** (np.arange(0, rot_dim, 2)[: rot_dim // 2].astype(np.float64) / rot_dim))
+    ang = np.repeat(np.arange(seq, dtype=np.float64)[:, None] * freqs[None, :], 2, axis=-1)      # (seq, rot_dim): n -> (n r), r = 2
+    x = t[..., :rot_dim]
+    xr = x.reshape(*x.shape[:-1], rot_dim // 2, 2)
+    half = np.stack((-xr[..., 1], xr[..., 0]), axis=-1).reshape(x.shape)                          # rotate_half
+    out = t.copy()
+    out[..., :rot_dim] = x * np.cos(ang) + half * np.sin(ang)
+    return out
+
+
+def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, *, n_heads, head_dim, window=8,
+             norm_eps=1e-5, version="two_residual", lambda_tok=1.0, lambda_char=1.0) -> np.ndarray:
+    """float64 restatement, line by line, of CustomLlamaModel.forward's gathers (inference.py:323-327) ->
+    TokenMixByCharBMMBlock.forward up to `h` (260-267) -> TokenMixByCharBMM.forward (189-238, swa_transform 174-179).
+    tokens (B, T), char_ids (B, T, c_v).  PARITY UNPINNED (see the section header).  numpy, small sizes only."""
+    f = np.float64
+    tok_table, char_table = np.asarray(tok_table, f), np.asarray(char_table, f)
+    toks = tok_table[np.asarray(tokens)]                                   # (b, t, d)        line 323
+    chars = char_table[np.asarray(char_ids)]                               # (b, t, c_v, d)   line 327
+    rms = lambda x, w: x / np.sqrt((x ** 2).mean(-1, keepdims=True) + norm_eps) * np.asarray(w, f)   # RMSNorm, 126-132
+    x, cn = rms(toks, attn_norm_w), rms(chars, char_norm_w)
+    b, t, c_v, _ = chars.shape
+    xq = x @ np.asarray(wq, f).T                                            # (b, t, bmm)      199
+    xk, xv = cn @ np.asarray(wk, f).T, cn @ np.asarray(wv, f).T             # (b, t, c_v, bmm) 200
+
+    def swa(a):                                                             # 174-179
+        pad = np.zeros((b, window - 1, c_v, a.shape[-1]), f)
+        a = np.concatenate([pad, a], axis=1).reshape(b, t + window - 1, -1)
+        unf = np.stack([a[:, i:i + t] for i in range(window)], axis=-1)     # unfold(1, window, 1): (b, t, c_v * bmm, window)
+        return unf.transpose(0, 1, 3, 2).reshape(b, t, c_v * window, -1)
+
+    xk, xv = swa(xk), swa(xv)                                               # (b, t, c_v * window, bmm) 201
+    nk = c_v * window
+    xq = xq.reshape(b, t, n_heads, head_dim).transpose(0, 2, 1, 3)          # (b, h, t, dh)   204, 211
+    xk = xk.reshape(b, t, nk, n_heads, head_dim).transpose(0, 3, 2, 1, 4)   # (b, h, nk, t, dh) 205, 213
+    xv = xv.reshape(b, t, nk, n_heads, head_dim)
+    xq = _rotary_rotate(xq, head_dim // 2)                                  # 215  (RotaryEmbedding(dim = head_dim // 2), 311)
+    xk = _rotary_rotate(xk, head_dim // 2)                                  # 216: the sequence axis (-2) is t here too
+    xk = xk.transpose(0, 1, 3, 2, 4)                                        # (b, h, t, nk, dh) 218
+    qk = np.einsum("bhtd,bhtkd->bhtk", xq, xk) / head_dim ** 0.5            # 221-222
+    qk = np.exp(qk - qk.max(-1, keepdims=True))
+    qk = qk / qk.sum(-1, keepdims=True)                                     # 223
+    xv = xv.transpose(0, 3, 1, 2, 4)                                        # (b, h, t, nk, dh) 228
+    y = np.einsum("bhtk,bhtkd->bhtd", qk, xv)                               # 231-232
+    y = y.transpose(0, 2, 1, 3).reshape(b, t, n_heads * head_dim)           # 233
+    h = y @ np.asarray(wo, f).T                                             # 235
+    if version == "one_residual":
+        h = h + toks                                                        # 264
+    elif version == "two_residual":
+        h = h + lambda_tok * toks + lambda_char * chars.mean(axis=-2)       # 267
+    return h

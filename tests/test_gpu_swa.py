@@ -1,0 +1,95 @@
+"""-m gpu: the sliding-window token <- character attention of the Llama character mixer (inference/inference.py:146-224) with
+the RMSNorms in front and the residuals behind it (226-267), through functional.char_swa and through the module mirror.
+
+PARITY UNPINNED BY THE REFERENCE: inference.py logs in to the HF hub at import (line 34) and its rotary embedding comes from
+a package that is absent here, so neither a run nor a fixture exists.  Checker: oracle.char_swa, a float64 numpy restatement
+line by line (the rotary step from the package's published algorithm).  Bar: 5e-6 of max|ref64|, as for the cross-attention
+mixin (fp32 kernels: three dense contractions over `dim`, a softmax and two norms)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as orc
+from util_gpu import DEV, dev, f32, host
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mot():
+    import mixture_of_tokenizers_amd as m
+    return m
+
+
+def case(seed, B, T, c_v, d, H, hd, Vt, Vc):
+    rs = np.random.RandomState(seed)
+    w = lambda *s: rs.standard_normal(s) / np.sqrt(s[-1])
+    return dict(toks=rs.randint(0, Vt, (B, T)).astype(np.int32), cid=rs.randint(0, Vc, (B, T, c_v)).astype(np.int64),
+                Et=f32(rs.standard_normal((Vt, d))), Ec=f32(rs.standard_normal((Vc, d))),
+                wa=f32(1 + 0.1 * rs.standard_normal(d)), wc=f32(1 + 0.1 * rs.standard_normal(d)),
+                wq=f32(w(H * hd, d)), wk=f32(w(H * hd, d)), wv=f32(w(H * hd, d)), wo=f32(w(d, H * hd)))
+
+
+@pytest.mark.parametrize("B,T,c_v,d,H,hd,window,version,seed", [
+    (2, 40, 8, 256, 4, 64, 8, "two_residual", 1),        # the reference's geometry (8 x 8 keys), small dims
+    (1, 7, 8, 256, 4, 64, 8, "two_residual", 2),         # a row shorter than the window: every query sees padding keys
+    (3, 33, 8, 512, 4, 128, 8, "one_residual", 3),       # head_dim 128
+    (2, 50, 5, 128, 2, 64, 6, "no_residual", 4),         # 30 keys: lanes beyond the keys idle
+    (1, 300, 8, 2048, 32, 64, 8, "two_residual", 5),     # config-5 dims: Llama-3.2-1B hidden 2048, 32 heads x 64
+])
+def test_char_swa_vs_oracle(mot, B, T, c_v, d, H, hd, window, version, seed):
+    Vt, Vc = 700, 132
+    c = case(seed, B, T, c_v, d, H, hd, Vt, Vc)
+    lt, lc = 0.8, 1.3
+    ref = orc.char_swa(c["toks"], c["cid"], c["Et"], c["Ec"], c["wa"], c["wc"], c["wq"], c["wk"], c["wv"], c["wo"], n_heads=H, head_dim=hd,
+                       window=window, norm_eps=1e-5, version=version, lambda_tok=lt, lambda_char=lc)
+    g = {k: dev(v) for k, v in c.items()}
+    two = version == "two_residual"
+    x = mot.functional.char_swa(g["toks"], g["cid"], g["Et"], g["Ec"], attn_norm_w=g["wa"], char_norm_w=g["wc"], wq=g["wq"], wk=g["wk"],
+                                wv=g["wv"], wo=g["wo"], n_heads=H, head_dim=hd, window=window, norm_eps=1e-5, version=version,
+                                lambda_tok=torch.tensor([lt], device=DEV) if two else None, lambda_char=torch.tensor([lc], device=DEV) if two else None)
+    mot.check_status()
+    assert x.shape == (B, T, d) and x.dtype == torch.float32
+    err = np.abs(host(x).astype(np.float64) - ref).max()
+    assert err <= 5e-6 * np.abs(ref).max(), f"max abs err {err:.3e} vs max|ref| {np.abs(ref).max():.3e}"
+
+
+def test_char_mixer_modules(mot):
+    """The module mirror (ModelArgs, RMSNorm, FeedForward, TokenMixByCharBMM[Block], CharMixerFrontEnd): the reference's parameter
+    names, h from the fused call, the feed-forward in torch on top; a window never leaves its batch row."""
+    from mixture_of_tokenizers_amd import modules as M
+    args = M.ModelArgs(version="two_residual", n_heads=4, dim=256, intermediate_dim=512, head_dim=64, norm_eps=1e-5)
+    torch.manual_seed(7)
+    fe = M.CharMixerFrontEnd(500, 132, args).to(DEV)
+    keys = sorted(fe.state_dict())
+    assert "char_token_mixer.tok_attention.wq.weight" in keys and "char_token_mixer.char_norm.weight" in keys
+    assert "char_token_mixer.lambda_tok" in keys and "char_token_mixer.feed_forward.w3.weight" in keys and "char_token_mixer.current_step" in keys
+    blk = fe.char_token_mixer
+    with torch.no_grad():
+        blk.lambda_tok.fill_(0.9); blk.lambda_char.fill_(0.4)
+        blk.attention_norm.weight.uniform_(0.8, 1.2); blk.char_norm.weight.uniform_(0.8, 1.2)
+    rs = np.random.RandomState(8)
+    toks, cid = rs.randint(0, 500, (3, 21)).astype(np.int64), rs.randint(0, 132, (3, 21, 8)).astype(np.int64)
+    with torch.no_grad():
+        h = blk.mix(fe.embed_tokens(dev(toks)), fe.char_embeddings(dev(cid)))
+        out = fe(dev(toks), dev(cid))
+    p = {k: host(v).astype(np.float64) for k, v in fe.state_dict().items()}
+    ta = "char_token_mixer.tok_attention."
+    ref = orc.char_swa(toks, cid, p["embed_tokens.weight"], p["char_embeddings.weight"], p["char_token_mixer.attention_norm.weight"],
+                       p["char_token_mixer.char_norm.weight"], p[ta + "wq.weight"], p[ta + "wk.weight"], p[ta + "wv.weight"], p[ta + "wo.weight"],
+                       n_heads=4, head_dim=64, window=8, norm_eps=1e-5, version="two_residual", lambda_tok=0.9, lambda_char=0.4)
+    assert np.abs(host(h).astype(np.float64) - ref).max() <= 5e-6 * np.abs(ref).max()
+    with torch.no_grad():
+        want = h + blk.feed_forward(blk.ffn_norm(h))
+    assert torch.equal(out, want)
+    # rows are independent: the same sequence alone gives the same rows
+    with torch.no_grad():
+        h1 = blk.mix(fe.embed_tokens(dev(toks[1:2])), fe.char_embeddings(dev(cid[1:2])))
+    assert torch.allclose(h1[0], h[1], rtol=0, atol=0)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        blk.mix(fe.embed_tokens(dev(toks)), fe.char_embeddings(dev(cid)))
+    bad = cid.copy(); bad[0, 3, 2] = 132
+    with torch.no_grad():
+        blk.mix(fe.embed_tokens(dev(toks)), fe.char_embeddings(dev(bad)))
+    with pytest.raises(IndexError):
+        mot.check_status()
