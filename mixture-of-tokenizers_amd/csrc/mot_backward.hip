@@ -1573,7 +1573,9 @@ __global__ __launch_bounds__(kThreads) void transpose_bf16_kernel(const __bf16 *
 }
 
 static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
+size_t embed_mix_bwd_mean_workspace_bytes(const MotEmbedMixDesc &d);
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
+    if (d.mode == MOT_MIX_MEAN) return embed_mix_bwd_mean_workspace_bytes(d);
     if (d.mode == MOT_MIX_CONCAT_LINEAR) {
         return (lin_bwd_layout(d).total + (d.dtype == MOT_BF16 ? up_layout(d).total : 0)) * 4 + 256 + (du16_usable(d) ? du16_layout(d).total : 0);
     }
@@ -1716,11 +1718,136 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     return run_scatter<MOT_MIX_CONCAT_LINEAR>(A, d, sort_ints, rn, stream);
 }
 
+// ==========================================================================================
+// MEAN backward:  x = s_t a + s_c mean_k v_k,  v = rms_norm?(E_c[id])      (inference/inference.py:266-267 under autograd)
+// The character table has a few hundred rows at most (132), so its gradient is a dense product instead of a scatter:
+//   cnt[n][r] = number of slots of token n holding character r                  (mean_counts_kernel)
+//   M1 = cnt^T G   [rows, D]                                                    (gemm_tn: fp32 MFMA, split over the tokens)
+//   S  = G V^T     [N, rows],   w_r = sum_n cnt[n][r] S[n][r]                   (gemm_rows + mean_colsum_kernel)
+//   d E_c[r] += (s_c / bpt) rn_r (M1[r] - v_r w_r / D)   (no norm: (s_c / bpt) M1[r]);   d s_c += sum_r w_r / bpt
+// S and w are only needed for the norm's backward and for d s_c.  The token side is the tokens-only backward with a scale.
+// ==========================================================================================
+__global__ __launch_bounds__(kThreads) void mean_counts_kernel(const int64_t *__restrict__ ids, int64_t n, int bpt, int rows, int ld,
+                                                               float *__restrict__ cnt, uint32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    if (t >= n) return;
+    int64_t v = lane < bpt ? ids[t * bpt + lane] : -1;
+    if (lane < bpt && (uint64_t)v >= (uint64_t)rows) { if (status) atomicOr(status, kStatusByteOor); v = 0; }
+    const int id = (int)v;
+    for (int r0 = 0; r0 < ld; r0 += 64) {
+        const int r = r0 + lane;
+        float c = 0.f;
+        for (int k = 0; k < bpt; ++k) c += __builtin_amdgcn_readlane(id, k) == r ? 1.f : 0.f;
+        if (r < ld) cnt[t * ld + r] = c;
+    }
+}
+
+// w[r] += sum_n cnt[n][r] * S[n][r]: a workgroup takes a stretch of tokens, a thread a column (rows <= 1024)
+__global__ __launch_bounds__(kThreads) void mean_colsum_kernel(const float *__restrict__ cnt, const float *__restrict__ S, int64_t n, int rows, int ld,
+                                                               int64_t per_block, float *__restrict__ w) {
+    const int64_t n0 = (int64_t)blockIdx.x * per_block, n1 = min(n, n0 + per_block);
+    for (int r = threadIdx.x; r < rows; r += kThreads) {
+        float acc = 0.f;
+        for (int64_t t = n0; t < n1; ++t) acc += cnt[t * ld + r] * S[t * ld + r];
+        if (acc != 0.f) atomicAdd(w + r, acc);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void mean_finalize_kernel(const float *__restrict__ M1, const float *__restrict__ table, const float *__restrict__ rn,
+                                                                 const float *__restrict__ w, int rows, int D, int bpt, const float *scale_byte,
+                                                                 float *__restrict__ d_table, float *d_scale) {
+    const float c = (scale_byte ? *scale_byte : 1.0f) / (float)bpt;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < (int64_t)rows * D; i += (int64_t)gridDim.x * kThreads) {
+        const int r = (int)(i / D);
+        float g = M1[i];
+        if (rn) g = rn[r] * (g - (table[i] * rn[r]) * (w[r] / (float)D));
+        d_table[i] += c * g;
+    }
+    if (d_scale && blockIdx.x == 0 && threadIdx.x < 64) {
+        float sacc = 0.f;
+        for (int r = threadIdx.x; r < rows; r += 64) sacc += w[r];
+        sacc = wave_sum(sacc);
+        if (threadIdx.x == 0) atomicAdd(d_scale, sacc / (float)bpt);
+    }
+}
+
+constexpr int64_t kMeanSlab = 65536;
+struct MeanBwdLayout { size_t rn, vn, m1, w, cnt, s, scatter, total; int ld; };
+static MeanBwdLayout mean_bwd_layout(const MotEmbedMixDesc &d) {
+    MeanBwdLayout L;
+    const int64_t N = d.n_rows * d.tokens_per_row, slab = N < kMeanSlab ? N : kMeanSlab;
+    L.ld = (int)((d.byte_rows + 3) & ~3);
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
+    L.rn = take(d.byte_rows); L.vn = take((size_t)d.byte_rows * d.byte_dim); L.m1 = take((size_t)d.byte_rows * d.byte_dim); L.w = take(d.byte_rows);
+    L.cnt = take((size_t)slab * L.ld); L.s = take((size_t)slab * L.ld); L.scatter = take(scatter_ws_ints(d)); L.total = o;
+    return L;
+}
+
+__global__ __launch_bounds__(kThreads) void scale_rows_kernel(const float *__restrict__ src, const float *__restrict__ rn, int rows, int D, float *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < (int64_t)rows * D; i += (int64_t)gridDim.x * kThreads) dst[i] = src[i] * rn[i / D];
+}
+
+static int launch_embed_mix_bwd_mean(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream) {
+    if (d.dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: the MEAN mode's backward is built for fp32 tables");
+    if (d.norm_out) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: MEAN with an output norm has no backward (the reference's residual, inference.py:267, has none)");
+    if (d.id_source != MOT_IDS_GIVEN || d.ids_b) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd MEAN: one given id tensor");
+    if (d.byte_rows > 1024) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd MEAN: %lld character rows (> 1024): the dense formulation is for small tables", (long long)d.byte_rows);
+    if (!gr.d_byte_table) return set_error(MOT_EINVAL, "embed_mix_bwd: d_byte_table missing");
+    const MeanBwdLayout L = mean_bwd_layout(d);
+    if (!d.workspace || d.workspace_bytes < L.total * 4) return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
+    float *ws = (float *)d.workspace;
+    const int64_t N = d.n_rows * d.tokens_per_row, slab = N < kMeanSlab ? N : kMeanSlab;
+    const int rows = (int)d.byte_rows, D = d.byte_dim;
+    const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    int rc;
+    // ---- token side: x = s_t * norm?(E_t[tok]) + (...) is the tokens-only mix as far as the token table and s_t are concerned
+    {
+        MotEmbedMixDesc t = d;
+        t.mode = MOT_MIX_NOOP; t.bpt = 0; t.id_source = MOT_IDS_NONE; t.ids_a = nullptr; t.byte_table = nullptr; t.norm_byte = 0; t.scale_byte = nullptr;
+        MotEmbedMixGrads gt = gr;
+        gt.d_byte_table = nullptr; gt.d_scale_byte = nullptr;
+        BwdArgs A;
+        fill_bwd_args(A, t, gt);
+        if ((rc = run_scatter<MOT_MIX_NOOP>(A, t, (int32_t *)(ws + L.scatter), nullptr, stream))) return rc;
+    }
+    // ---- character side
+    const float *V = (const float *)d.byte_table, *rn = nullptr;
+    const bool need_s = d.norm_byte || gr.d_scale_byte;
+    if (d.norm_byte) {
+        if ((rc = launch_rows_rnorm(d.byte_table, rows, D, eps, ws + L.rn, MOT_F32, stream))) return rc;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(256), dim3(kThreads), 0, stream, (const float *)d.byte_table, ws + L.rn, rows, D, ws + L.vn);
+        V = ws + L.vn; rn = ws + L.rn;
+    }
+    if ((rc = launch_zero_words(ws + L.m1, (int64_t)rows * D, stream))) return rc;
+    if ((rc = launch_zero_words(ws + L.w, rows, stream))) return rc;
+    for (int64_t n0 = 0; n0 < N; n0 += slab) {
+        const int64_t nn = N - n0 < slab ? N - n0 : slab;
+        const float *G = (const float *)gr.grad_out + n0 * D;
+        hipLaunchKernelGGL(mean_counts_kernel, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.ids_a + n0 * d.bpt, nn, d.bpt, rows,
+                           L.ld, ws + L.cnt, d.status);
+        if ((rc = check_launch("mean_counts_kernel"))) return rc;
+        if ((rc = launch_gemm_tn(ws + L.cnt, L.ld, rows, G, D, D, nn, ws + L.m1, D, stream))) return rc;
+        if (need_s) {
+            if ((rc = launch_gemm_rows(G, D, nn, V, D, D, rows, ws + L.s, L.ld, true, stream))) return rc;
+            const int64_t per = 256;
+            hipLaunchKernelGGL(mean_colsum_kernel, dim3((unsigned)((nn + per - 1) / per)), dim3(kThreads), 0, stream, ws + L.cnt, ws + L.s, nn, rows, L.ld, per,
+                               ws + L.w);
+            if ((rc = check_launch("mean_colsum_kernel"))) return rc;
+        }
+    }
+    hipLaunchKernelGGL(mean_finalize_kernel, dim3(256), dim3(kThreads), 0, stream, ws + L.m1, (const float *)d.byte_table, rn, ws + L.w, rows, D, d.bpt,
+                       d.scale_byte, (float *)gr.d_byte_table, gr.d_scale_byte);
+    return check_launch("mean_finalize_kernel");
+}
+
+size_t embed_mix_bwd_mean_workspace_bytes(const MotEmbedMixDesc &d) { return mean_bwd_layout(d).total * 4; }
+
 int launch_embed_mix_bwd(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream) {
     if (d.n_rows * d.tokens_per_row > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: more than 2^31 tokens");
     if (d.mode == MOT_MIX_CONCAT_LINEAR) return launch_embed_mix_bwd_linear(d, gr, stream);
-    if (d.mode != MOT_MIX_SUM && d.mode != MOT_MIX_NOOP)
-        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: the MEAN mode is forward-only (mode %d)", d.mode);
+    if (d.mode == MOT_MIX_MEAN) return launch_embed_mix_bwd_mean(d, gr, stream);
     if (d.mode == MOT_MIX_SUM && d.id_source != MOT_IDS_GIVEN)
         return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
     BwdArgs A;

@@ -321,7 +321,7 @@ def embed_mix_plan(tokens, tok_table, byte_table=None, **kw) -> EmbedMixPlan:
     return _embed_mix_fwd(tokens, tok_table, byte_table, _plan=True, **kw)
 
 
-_BWD_MODES = ("sum", "noop", "concat_linear")
+_BWD_MODES = ("sum", "noop", "concat_linear", "mean")
 
 
 class _EmbedMixFn(torch.autograd.Function):

@@ -456,3 +456,38 @@ def test_full_size_backward_properties(mot):
                                 mode="sum", bpt=bpt, dtype=np.float64, norm_out=True)
         if len(np.flatnonzero(flat == tok)) <= 64:      # all of the token's positions were included: its row must match
             assert rel(host(r1["tok_table"][tok]), sub["tok_table"][tok]) < TOL, tok
+
+
+@pytest.mark.parametrize("D,bpt,Vt,Vc,B,T,kw,seed", [
+    (256, 8, 500, 132, 3, 100, dict(scaled=True), 9601),                          # the two_residual residual (inference.py:267): both lambdas
+    (128, 8, 300, 132, 2, 77, dict(norm_byte=True, scaled=True), 9602),           # per-character rms norm: its backward needs S = G V^T
+    (64, 5, 100, 40, 1, 70001, dict(norm_tok=True, norm_byte=True), 9603),        # more tokens than one slab of the dense products
+    (2048, 8, 700, 132, 1, 300, dict(scaled=True), 9604),                         # config-5 width
+])
+def test_mean_backward_vs_oracle(mot, D, bpt, Vt, Vc, B, T, kw, seed):
+    """Backward of the MEAN mix (x = s_t a + s_c mean_k v_k): token-table scatter + the character table's gradient as dense
+    products over the token axis.  float64 oracle (parity unpinned by the reference, whose inference file never trains), through
+    autograd: embed_mix records the node, loss.backward() fills .grad."""
+    kw = dict(kw)
+    scaled = kw.pop("scaled", False)
+    rs = np.random.RandomState(seed)
+    toks = rs.randint(0, Vt, (B, T)).astype(np.int32)
+    ids = rs.randint(0, Vc, (B, T * bpt)).astype(np.int64)
+    Et, Ec = f32(gi.normal_table(seed + 1, Vt, D)), f32(gi.normal_table(seed + 2, Vc, D))
+    g = f32(rs.standard_normal((B, T, D)))
+    okw, gkw = dict(kw), dict(kw)
+    pt, pc = torch.nn.Parameter(dev(Et)), torch.nn.Parameter(dev(Ec))
+    if scaled:
+        okw.update(scale_tok=0.8, scale_byte=1.3)
+        st, sb = torch.nn.Parameter(torch.tensor([0.8], device=DEV)), torch.nn.Parameter(torch.tensor([1.3], device=DEV))
+        gkw.update(scale_tok=st, scale_byte=sb)
+    ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Ec.astype(np.float64), g.astype(np.float64), mode="mean", bpt=bpt,
+                            dtype=np.float64, **okw)
+    x = mot.embed_mix(dev(toks), pt, pc, mode="mean", bpt=bpt, ids_a=dev(ids), **gkw)
+    (x * dev(g)).sum().backward()
+    mot.check_status()
+    assert rel(host(pt.grad), ref["tok_table"]) < TOL
+    assert rel(host(pc.grad), ref["byte_table"]) < TOL
+    if scaled:
+        scale = _scalar_scale(ref["scales"], B * T, D)
+        assert abs(float(st.grad) - ref["scales"][0]) < TOL * scale and abs(float(sb.grad) - ref["scales"][1]) < TOL * scale
