@@ -761,6 +761,306 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Lane-contiguous variant for the headline shapes: SUM / NOOP, fp32, D = 64 NE with NE a multiple of 4, and (SUM) a byte slot
+// made of whole lanes (Db a multiple of NE, i.e. 64 / bpt lanes per slot: bpt a power of two).  A lane owns NE CONSECUTIVE
+// elements of a row, so
+//   * a gradient row, a token row and the lane's piece of a byte row are NE / 4 16-byte loads each (the strided layout of
+//     embed_mix_bwd_full_kernel needs NE 4-byte loads: four times the vector-memory instructions per position, and the
+//     position rate of that kernel was what its address unit could issue);
+//   * a lane belongs to ONE byte slot: one id, one row offset, one rms factor per lane, no cross-lane hand-out; the per-slot
+//     sums of the byte-norm backward are a lane-local sum plus a log2(64 / bpt)-step exchange inside the slot's lane group;
+//   * 12 waves per workgroup (one workgroup per CU: the privatised byte-table gradient takes most of the LDS), each with the
+//     NEXT position's gradient row already requested while it works on the current one: the kernel streams 1.6 GB of gradient
+//     rows, and one 3 KB row in flight per wave (16 waves: 48 KB per CU) covered 60 % of what HBM latency x bandwidth asks for;
+//   * the privatised table's rows are Db + 1 sums apart: with a stride of Db = 48 64-bit words every row starts on one of two
+//     bank offsets and a wave's 64 adds met on 8 bank positions (SQ_LDS_BANK_CONFLICT was a quarter of the kernel's cycles).
+// The token-table flush wants 256 contiguous bytes per atomic wave-instruction (lane-contiguous pieces would spread each
+// instruction over 3 KB: ~12x the memory-side atomic requests), so a run's gradient row is transposed through a per-wave LDS
+// buffer once per run (a run of equal tokens is ~17 positions long on FineWeb-shaped ids).
+// ------------------------------------------------------------------------------------------
+constexpr int kLcThreads = 768, kLcWaves = kLcThreads / 64;   // 12 waves, 3 per SIMD: ~170 registers per lane, room for the next position's gradient row
+
+template <int MODE, int NE, bool DUAL>
+__global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdArgs A) {
+#pragma clang fp contract(fast)   // fused multiply-adds here: the sums below are compared with float64 at 2e-5, not bit for bit
+    constexpr int D = 64 * NE, NV = NE / 4;
+    constexpr bool BYTES = MODE != MOT_MIX_NOOP;
+    extern __shared__ unsigned long long lds_q[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = A.Db + 1;                                      // row stride of the privatised sums, in 64-bit words
+    const int nbyte = (A.priv_rows * qs + 1) & ~1;
+    unsigned long long *dbyte_q = lds_q;
+    uint32_t *fx_bits = (uint32_t *)(lds_q + nbyte);
+    float *xp = (float *)(lds_q + nbyte + 2) + wave * D;          // this wave's transposition buffer (16-byte aligned: nbyte is even)
+    for (int i = tid; i < nbyte; i += kLcThreads) dbyte_q[i] = 0ull;
+    if (tid == 0) *fx_bits = 0u;
+    const float s_tok = A.scale_tok ? *A.scale_tok : 1.0f;
+    const float s_byte = A.scale_byte ? *A.scale_byte : 1.0f;
+    const float inv_d = 1.0f / (float)D;
+    // the lane's place: byte slot, first element inside the slot's row
+    const int lps = BYTES ? A.Db / NE : 64;                       // lanes per slot
+    const int slot = BYTES ? lane / lps : 0;
+    const int wi0 = BYTES ? (lane - slot * lps) * NE : 0;
+    const uint32_t lane_off = (uint32_t)lane * (NE * 4u);
+    auto load_row = [&](const char *rbase, float (&dst)[NE]) {   // NE consecutive floats at rbase + lane_off
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4v w = *(const float4v *)(rbase + (lane_off + 16u * v));
+            dst[4 * v] = w.x; dst[4 * v + 1] = w.y; dst[4 * v + 2] = w.z; dst[4 * v + 3] = w.w;
+        }
+    };
+    auto load_byte_row = [&](int id, float (&dst)[NE]) { load_row((const char *)(A.byte_table + (int64_t)id * A.Db + wi0) - lane_off, dst); };
+    auto slot_sum = [&](float v) {                                // sum over the lanes of this lane's slot (lps a power of two)
+        for (int o = 1; o < lps; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    int fx_k = 0;
+    float fx_mul = 1.f;                                           // s_byte * 2^fx_k: a byte-row term's fixed-point value is dy * fx_mul
+    auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
+
+    float acc[NE], an[NE];
+    float ra = 1.f, ds_t = 0.f, ds_b = 0.f;
+    int cur = -1;
+    auto flush = [&]() {
+        if (cur < 0) return;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) *(float4v *)(xp + lane * NE + 4 * v) = float4v{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
+        seg_sync();
+        float *drow = A.d_tok + (int64_t)cur * D;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) atomicAdd(drow + lane + 64 * j, xp[lane + 64 * j]);
+        seg_sync();
+    };
+    const int64_t per_wg = (A.n_tokens + gridDim.x - 1) / gridDim.x;
+    const int64_t wg_lo = min(A.n_tokens, (int64_t)blockIdx.x * per_wg), wg_hi = min(A.n_tokens, wg_lo + per_wg);
+    const int64_t per_wave = (wg_hi - wg_lo + kLcWaves - 1) / kLcWaves;
+    const int64_t s_begin = min(wg_hi, wg_lo + wave * per_wave), s_end = min(wg_hi, s_begin + per_wave);
+    __syncthreads();   // orders the table zeroing above
+    if (BYTES) {       // fixed-point scale of the privatised sums, as in embed_mix_bwd_full_kernel: every wave takes part
+        float gmax = 0.f;
+        if (s_begin < s_end) {
+            float gs[NE];
+            load_row((const char *)(A.grad_out + (int64_t)A.pos_sorted[s_begin] * D), gs);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) gmax = fmaxf(gmax, fabsf(gs[j]));
+            gmax = wave_max(gmax) * fabsf(s_byte);
+            if (lane == 0 && gmax > 0.f && gmax < INFINITY) atomicMax(fx_bits, __float_as_uint(gmax));
+        }
+        __syncthreads();
+        const float m = __uint_as_float(*fx_bits);
+        fx_k = m > 0.f ? min(27 - ilogbf(m), 100) : 0;
+        fx_mul = ldexpf(s_byte, fx_k);
+    }
+    // the id of this lane's slot: requested raw, range-checked where it is first used (a check right behind the load would make
+    // the wave wait for everything it has in flight)
+    auto load_id = [&](const int64_t *ids, int64_t n) { return *(const int64_t *)((const char *)(ids + n * A.bpt) + (uint32_t)slot * 8u); };
+    auto clamp_id = [&](int64_t v) {
+        if ((uint64_t)v >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); v = 0; }
+        return (int)v;
+    };
+    // Three positions are in flight per wave: k is being worked on, the rows of k + 1 (gradient row, byte rows) and the byte
+    // ids of k + 2 have been requested.  Positions come 64 (position, token) pairs at a time, handed out with readlane.
+    for (int64_t s0 = s_begin; s0 < s_end; s0 += 64) {
+        const int cnt = (int)min((int64_t)64, s_end - s0);
+        int vpos = 0, vtok = 0;
+        if (lane < cnt) { vpos = A.pos_sorted[s0 + lane]; vtok = A.tok_sorted[s0 + lane]; }
+        const int n0 = __builtin_amdgcn_readfirstlane(vpos), n1 = __builtin_amdgcn_readlane(vpos, cnt > 1 ? 1 : 0);
+        float g_nx[NE], b_nx[NE], rn_nx = 1.f;
+        int ida_nx = 0, idb_nx = 0;
+        int64_t ida_n2 = 0, idb_n1 = 0;                           // raw: the first id tensor's entry two positions ahead, the second's one ahead
+        load_row((const char *)(A.grad_out + (int64_t)n0 * D), g_nx);
+        if (BYTES) {
+            ida_nx = clamp_id(load_id(A.ids_a, n0));
+            if (DUAL) idb_nx = clamp_id(load_id(A.ids_b, n0));
+            ida_n2 = load_id(A.ids_a, n1);
+            if (DUAL) idb_n1 = load_id(A.ids_b, n1);
+            load_byte_row(ida_nx, b_nx);
+            if (A.norm_byte) rn_nx = A.byte_rnorm[ida_nx];
+        }
+        for (int k = 0; k < cnt; ++k) {
+            const int tok = __builtin_amdgcn_readlane(vtok, k), ida = ida_nx, idb = idb_nx;
+            const bool more = k + 1 < cnt, newrun = tok != cur;
+            float dy[NE], bn[NE];
+            const float rnb = rn_nx;
+#pragma unroll
+            for (int j = 0; j < NE; ++j) { dy[j] = g_nx[j]; bn[j] = BYTES ? b_nx[j] : 0.f; }
+            // Requests are issued oldest-needed first (a wave's loads return in order): what THIS position still lacks -- a new
+            // run's token row, the second id tensor's byte row -- goes out before the next position's rows, so that waiting for
+            // it leaves those in flight.
+            float b2[NE];
+            if constexpr (DUAL) load_byte_row(idb, b2);
+            if (newrun) {   // the previous token's gradient row leaves, this token's row comes in
+                flush();
+                cur = tok;
+                load_row((const char *)(A.tok_table + (int64_t)tok * D), an);
+            }
+            if (more) {   // the next position's rows, the byte ids of the one after
+                const int nn = __builtin_amdgcn_readlane(vpos, k + 1);
+                load_row((const char *)(A.grad_out + (int64_t)nn * D), g_nx);
+                if (BYTES) {
+                    ida_nx = clamp_id(ida_n2);
+                    if (DUAL) idb_nx = clamp_id(idb_n1);
+                    load_byte_row(ida_nx, b_nx);
+                    if (A.norm_byte) rn_nx = A.byte_rnorm[ida_nx];
+                    if (k + 2 < cnt) {
+                        const int n2 = __builtin_amdgcn_readlane(vpos, k + 2);
+                        ida_n2 = load_id(A.ids_a, n2);
+                        if (DUAL) idb_n1 = load_id(A.ids_b, n2);
+                    }
+                }
+            }
+            if constexpr (DUAL) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) bn[j] += b2[j];
+            }
+            if (newrun) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) acc[j] = 0.f;
+                ra = 1.f;
+                if (A.norm_tok) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) ss += an[j] * an[j];
+                    ra = rms_scale(wave_sum(ss), D, A.eps);
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) an[j] *= ra;
+                }
+            }
+            if (BYTES && A.norm_byte) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) bn[j] *= rnb;
+            }
+            // ---- back through the output norm: x = ry y, dy = ry (g - x mean(g x)) = ry g - (ry^3 sum(g y) / D) y
+            if (A.norm_out) {
+                float y[NE], ss = 0.f, m = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) {
+                    y[j] = BYTES ? an[j] * s_tok + bn[j] * s_byte : an[j] * s_tok;
+                    ss += y[j] * y[j];
+                    m += dy[j] * y[j];
+                }
+                const float ry = rms_scale(wave_sum(ss), D, A.eps);
+                const float c2 = wave_sum(m) * inv_d * ry * ry * ry;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) dy[j] = ry * dy[j] - c2 * y[j];
+            }
+            // ---- token side
+            {
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) dot += dy[j] * an[j];
+                ds_t += dot;
+                if (A.norm_tok) {
+                    const float c = wave_sum(dot) * s_tok * inv_d, rs = ra * s_tok;   // ra (s_t dy - a_n mean(s_t dy . a_n))
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) acc[j] += rs * dy[j] - (ra * c) * an[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) acc[j] += dy[j] * s_tok;
+                }
+            }
+            // ---- byte side
+            if (BYTES) {
+                float dot = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) dot += dy[j] * bn[j];
+                ds_b += dot;
+                if (A.norm_byte) {   // v = r_row (db - b_n mean_slot(db b_n)), db = s_b dy: the slot is this lane's group
+                    const float sg = slot_sum(dot) / (float)A.Db;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) dy[j] = rnb * (dy[j] - bn[j] * sg);
+                }
+                // Fixed-point sums in LDS: x = dy s_b 2^fx_k rounded to a 32-bit integer, added into 64-bit words.  A lane takes
+                // this path with all its NE terms or not at all: it must have an LDS row, and its largest |x| must convert
+                // (< 2^31; the comparison is false for NaN / infinity too).  The absolute rounding error of a term is
+                // <= 2^-(fx_k + 1), i.e. 2^-28 of the workgroup's sampled |g s_b| maximum -- below what a float atomic loses on
+                // a row's running sum -- so small terms need no path of their own.  Lanes that fail (a term > 16x the sample
+                // maximum, a non-finite term, a row beyond the privatised ones) add exact global float atomics instead.
+                const int sa = byte_slot(ida), sb = DUAL ? byte_slot(idb) : 0;
+                float amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < NE; ++j) { dy[j] *= fx_mul; amax = fmaxf(amax, fabsf(dy[j])); }
+                const bool fits = amax < 0x1p31f;
+                const bool oka = fits && sa >= 0, okb = DUAL ? (fits && sb >= 0) : true;
+                if (__all(oka && okb)) {
+                    unsigned long long *ra_q = dbyte_q + (size_t)sa * qs + wi0, *rb_q = dbyte_q + (size_t)sb * qs + wi0;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const unsigned long long q = (unsigned long long)(long long)__float2int_rn(dy[j]);
+                        atomicAdd(ra_q + j, q);
+                        if (DUAL) atomicAdd(rb_q + j, q);
+                    }
+                } else {
+                    const float back = ldexpf(1.0f, -fx_k);       // x 2^-fx_k: the term itself, exactly
+                    unsigned long long *ra_q = dbyte_q + (size_t)max(sa, 0) * qs + wi0, *rb_q = dbyte_q + (size_t)max(sb, 0) * qs + wi0;
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) {
+                        const unsigned long long q = (unsigned long long)(long long)__float2int_rn(fits ? dy[j] : 0.f);
+                        const float v = dy[j] * back;
+                        if (oka) atomicAdd(ra_q + j, q); else if (v != 0.f) atomicAdd(A.d_byte + (int64_t)ida * A.Db + wi0 + j, v);
+                        if (DUAL) { if (okb) atomicAdd(rb_q + j, q); else if (v != 0.f) atomicAdd(A.d_byte + (int64_t)idb * A.Db + wi0 + j, v); }
+                    }
+                }
+            }
+        }
+    }
+    flush();
+    if (A.d_scale_tok) { ds_t = wave_sum(ds_t); if (lane == 0) atomicAdd(A.d_scale_tok, ds_t); }
+    if (BYTES && A.d_scale_byte) { ds_b = wave_sum(ds_b); if (lane == 0) atomicAdd(A.d_scale_byte, ds_b); }
+    if (BYTES) {
+        __syncthreads();
+        for (int i = tid; i < A.priv_rows * A.Db; i += kLcThreads) {
+            const int sl = i / A.Db, wi = i - sl * A.Db;
+            const long long q = (long long)dbyte_q[sl * qs + wi];
+            if (q == 0) continue;
+            const int row = sl < A.priv_lo ? sl : sl - A.priv_lo + A.priv_hi0;
+            atomicAdd(A.d_byte + row * A.Db + wi, (float)ldexp((double)q, -fx_k));
+        }
+    }
+}
+
+template <int MODE>
+static bool lc_layout(const BwdArgs &A) {
+    if (A.in_bf16 || (A.D & 255) || A.Dt != A.D || A.tok_lo != 0 || A.D > 1024) return false;
+    const int ne = A.D / 64;
+    if (MODE == MOT_MIX_SUM) {
+        if (A.byte_lo != 0 || A.nbk != A.D || A.Db % ne) return false;
+        const int lps = A.Db / ne;
+        if (lps & (lps - 1)) return false;                        // the slot sums exchange inside power-of-two lane groups
+        if (A.ids_b && ne > 12) return false;                     // two id tensors at 1024 columns would spill
+    }
+    return ne == 4 || ne == 8 || ne == 12 || ne == 16;   // 1024-thread workgroups cap a lane at 128 registers: NE 24 / 32 would spill
+}
+
+template <int MODE, int NE, bool DUAL>
+static int launch_bwd_lc_t(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    static std::atomic<uint64_t> lds_ok{0};   // per-device bits
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_lc_kernel<MODE, NE, DUAL>, lds_ok, "embed_mix_bwd_lc_kernel")) return rc_lds;
+    int64_t blocks = (A.n_tokens + 16 * kLcWaves - 1) / (16 * kLcWaves);   // >= 16 sorted positions per wave
+    if (blocks > 256) blocks = 256;   // one workgroup per CU
+    hipLaunchKernelGGL((embed_mix_bwd_lc_kernel<MODE, NE, DUAL>), dim3((unsigned)blocks), dim3(kLcThreads), lds, stream, A);
+    return check_launch("embed_mix_bwd_lc_kernel");
+}
+template <int MODE, int NE>
+static int launch_bwd_lc(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    if constexpr (MODE == MOT_MIX_SUM) {
+        if (A.ids_b) return launch_bwd_lc_t<MODE, NE, true>(A, lds, stream);
+    }
+    return launch_bwd_lc_t<MODE, NE, false>(A, lds, stream);
+}
+
+template <int MODE>
+static int dispatch_ne_lc(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    switch (A.D / 64) {
+        case 4: return launch_bwd_lc<MODE, 4>(A, lds, stream);
+        case 8: return launch_bwd_lc<MODE, 8>(A, lds, stream);
+        case 12: return launch_bwd_lc<MODE, 12>(A, lds, stream);
+        default: return launch_bwd_lc<MODE, 16>(A, lds, stream);
+    }
+}
+
 // ---- grouping of the token positions by (clamped) token id: a counting sort in three small kernels.
 // bwd_rank_kernel: a workgroup sorts (token << 11 | index) for 2048 positions in LDS (bitonic), so equal tokens become
 // runs; the head of a run reserves the run's places in the token's group with ONE atomicAdd(counts[token], length)
@@ -994,7 +1294,10 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     if (d.tok_rows >= (1 << 21) - 1)   // (token << 11 | index) of bwd_rank_kernel must stay below its 0xffffffff padding key
         return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: token tables of %lld rows (>= 2^21 - 1) are not built", (long long)d.tok_rows);
     const bool full = full_layout<MODE>(A);
-    size_t lds = 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
+    bool lc = false;
+    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) lc = lc_layout<MODE>(A) && !(A.abl & 8);   // abl 8: dev switch back to the strided kernels
+    // LDS besides the privatised byte-table sums: per-wave per-slot accumulators (strided kernels) or per-wave transposition rows (lane-contiguous)
+    size_t lds = lc ? (size_t)kLcWaves * A.D * sizeof(float) + 16 : 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
     if ((rc = launch_group_positions(A.tokens, A.n_tokens, A.tok_rows, ws_ints, &A.pos_sorted, &A.tok_sorted, A.status, stream))) return rc;
 #ifdef MOT_DEV_ABLATION
     if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
@@ -1003,15 +1306,19 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     if (MODE != MOT_MIX_NOOP) {
         // as many byte-table rows as 150 KiB of LDS hold at 8 bytes per element; when not all fit, the last 32 rows
         // (pad / eot and other specials sit at the end of the byte vocabulary) and the first cap-32
-        const int64_t cap = (int64_t)((150 * 1024 - lds) / ((size_t)d.byte_dim * 8));
+        const size_t row_q = (size_t)d.byte_dim + (lc ? 1 : 0);   // the lane-contiguous kernel pads its rows by one sum
+        const int64_t cap = (int64_t)((150 * 1024 - lds) / (row_q * 8));
         if (cap >= d.byte_rows) { A.priv_lo = (int)d.byte_rows; A.priv_rows = (int)d.byte_rows; }
         else if (cap > 64) { A.priv_lo = (int)cap - 32; A.priv_hi0 = (int)d.byte_rows - 32; A.priv_rows = (int)cap; }
-        lds += (size_t)A.priv_rows * d.byte_dim * 8;
+        lds += (size_t)A.priv_rows * row_q * 8 + 8;
         if (d.norm_byte && !(MODE == MOT_MIX_CONCAT_LINEAR && d.ids_b)) {
             rc = launch_rows_rnorm(A.byte_table, d.byte_rows, d.byte_dim, A.eps, rnorm_ws, A.in_bf16 ? MOT_BF16 : MOT_F32, stream);
             if (rc) return rc;
             A.byte_rnorm = rnorm_ws;
         }
+    }
+    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
+        if (lc) return dispatch_ne_lc<MODE>(A, lds, stream);
     }
     if (full) return dispatch_ne_full<MODE>(A, lds, stream);
     return dispatch_ne<MODE>(A, lds, stream);
