@@ -479,34 +479,58 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
     const float inv_bpt = 1.0f / (float)A.bpt;
     const int64_t n_all = A.T;                                // tokens are addressed flat: A.T = n_rows * tokens_per_row here
     const int64_t n0 = part * tokens_per_part, n1 = min(n_all, n0 + tokens_per_part);
-    const int nch = slice_cols / (64 * VEC);                  // 16-byte chunks per lane (1 for the built shapes... general loop below)
     T *out = (T *)A.out;
-    for (int64_t tb = n0 + wave * U; tb < n1; tb += 16 * U) {
-        for (int ch = 0; ch < nch; ++ch) {
-            const int c = (lane + 64 * ch) * VEC;
-            typename Elem<T>::raw ar[U];
-            int idv[U];   // lanes < bpt: the token's character ids (one coalesced load; handed out by readlane below)
+    const int c = lane * VEC;                                 // one 16-byte chunk per lane: slice_cols == 64 * VEC (launcher)
+    // A wave takes a contiguous stretch of the part's tokens.  Memory operations of a wave complete in issue order, stores
+    // included: a batch whose loads were issued BEHIND the previous batch's stores (load, compute, store, load, ...) waited for
+    // those stores to reach HBM before it could touch its own data, and the token-row address came from a second dependent
+    // load -- 7 us per batch of four 1 KB row slices, 58 % of the roofline.  Now the token ids arrive 64 at a time, a lane each
+    // (handed out with readlane: the row address is scalar), a batch's character ids are ONE 8-byte load per lane, and batch
+    // b + 1 is requested before batch b is computed and stored, so that the wait for its data leaves the stores in flight.
+    const int64_t per_wave = (((n1 - n0 + 15) / 16) + U - 1) / U * U;
+    const int64_t w_lo = min(n1, n0 + wave * per_wave), w_hi = min(n1, w_lo + per_wave);
+    if (w_lo >= w_hi) return;                                 // no barrier below
+    const int id_lanes = U * A.bpt;                           // <= 64 (launcher)
+    int tokv_nx = w_lo + lane < w_hi ? A.tokens[w_lo + lane] : 0;
+    for (int64_t chunk = w_lo; chunk < w_hi; chunk += 64) {
+        const int tokv = tokv_nx;
+        if (chunk + 64 < w_hi) tokv_nx = chunk + 64 + lane < w_hi ? A.tokens[chunk + 64 + lane] : 0;
+        const int nb = (int)min((int64_t)64, w_hi - chunk);
+        typename Elem<T>::raw ar_nx[U];
+        int64_t id_nx = 0;
+        auto request = [&](int b) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t n = min(tb + u, n1 - 1);
-                int64_t cid = lane < A.bpt ? A.ids_a[n * A.bpt + lane] : 0;
-                if ((uint64_t)cid >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); cid = 0; }
-                idv[u] = (int)cid;
-                int tok = A.tokens[n];
+                int tok = __builtin_amdgcn_readlane(tokv, min(b + u, nb - 1));   // the tail re-reads the last token; its store is skipped
                 if ((uint64_t)(uint32_t)tok >= (uint64_t)A.tok_rows) {
                     if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
                     tok = 0;
                 }
-                ar[u] = Elem<T>::load_raw(tok_table + (int64_t)tok * D + col0 + c);
+                ar_nx[u] = Elem<T>::load_raw(tok_table + (int64_t)tok * D + col0 + c);
             }
+            const int64_t at = (chunk + b) * A.bpt + lane;    // lane = (token of the batch, slot)
+            id_nx = (lane < id_lanes && at < n_all * A.bpt) ? A.ids_a[at] : 0;
+        };
+        request(0);
+        for (int b = 0; b < nb; b += U) {
+            typename Elem<T>::raw ar[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) ar[u] = ar_nx[u];
+            const int64_t idq = id_nx;
+            if (b + U < nb) request(b + U);
+            // range check of the batch's ids, where they are used (one compare per lane; a bad id is flagged and reads row 0)
+            const bool bad = (uint64_t)idq >= (uint64_t)A.byte_rows;
+            if (bad && A.status) atomicOr(A.status, kStatusByteOor);
+            const int idv = bad ? 0 : (int)idq;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t n = tb + u;
+                const int64_t n = chunk + b + u;
                 // chars.mean(dim=-2), inference.py:267: four independent LDS reads per step (two accumulators keep the adds off one chain)
                 vec_t acc0 = (vec_t)(0.f), acc1 = (vec_t)(0.f);
+                const int l0 = u * A.bpt;
                 int k = 0;
                 for (; k + 4 <= A.bpt; k += 4) {
-                    const int i0 = __shfl(idv[u], k, 64), i1 = __shfl(idv[u], k + 1, 64), i2 = __shfl(idv[u], k + 2, 64), i3 = __shfl(idv[u], k + 3, 64);
+                    const int i0 = __shfl(idv, l0 + k, 64), i1 = __shfl(idv, l0 + k + 1, 64), i2 = __shfl(idv, l0 + k + 2, 64), i3 = __shfl(idv, l0 + k + 3, 64);
                     vec_t v0 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i0 * slice_cols + c));
                     vec_t v1 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i1 * slice_cols + c));
                     vec_t v2 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i2 * slice_cols + c));
@@ -515,7 +539,7 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                     acc0 += v0; acc1 += v1; acc0 += v2; acc1 += v3;
                 }
                 for (; k < A.bpt; ++k) {
-                    const int id = __shfl(idv[u], k, 64);
+                    const int id = __shfl(idv, l0 + k, 64);
                     vec_t v = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)id * slice_cols + c));
                     if (A.norm_byte) v *= A.byte_rnorm[id];
                     acc0 += v;
@@ -523,9 +547,9 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                 const vec_t acc = acc0 + acc1;
                 vec_t a = Elem<T>::widen(ar[u]);
                 if (A.scale_tok) a *= s_tok;
-                const vec_t b = acc * inv_bpt;                // exact for the power-of-two slot counts of the reference (8), else within an ulp of acc / bpt
-                const vec_t x = a + (A.scale_byte ? b * s_byte : b);
-                if (n < n1) Elem<T>::storev_nt(out + n * D + col0 + c, x);
+                const vec_t bsum = acc * inv_bpt;             // exact for the power-of-two slot counts of the reference (8), else within an ulp of acc / bpt
+                const vec_t x = a + (A.scale_byte ? bsum * s_byte : bsum);
+                if (b + u < nb) Elem<T>::storev_nt(out + n * D + col0 + c, x);
             }
         }
     }
@@ -542,8 +566,12 @@ static int launch_mean_lds(MixArgs A, const MotEmbedMixDesc &d, int slice_cols, 
     A.T = N;                                                  // flat token addressing (rows are independent without a pull)
     const size_t lds = (size_t)d.byte_rows * slice_cols * sizeof(T);
     static std::atomic<uint64_t> lds_ok{0};   // per-device bits
-    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, 4>, lds_ok, "embed_mean_lds_kernel")) return rc_lds;
-    hipLaunchKernelGGL((embed_mean_lds_kernel<T, 4>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
+#ifndef MOT_VAR_MEANU
+#define MOT_VAR_MEANU 4
+#endif
+    constexpr int kMeanU = MOT_VAR_MEANU;   // token-row slices in flight per wave
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU>, lds_ok, "embed_mean_lds_kernel")) return rc_lds;
+    hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
     return check_launch("embed_mean_lds_kernel");
 }
 
@@ -553,7 +581,7 @@ static int mean_lds_slice(const MotEmbedMixDesc &d) {
         d.out_ids_pulled || (d.flags & MOT_FLAG_MEAN_GENERIC))
         return 0;
     const int esize = d.dtype == MOT_BF16 ? 2 : 4, chunk = 64 * (16 / esize);   // columns one wave covers with 16-byte lanes
-    if (d.tok_dim % chunk || d.n_rows * d.tokens_per_row < 16384) return 0;
+    if (d.tok_dim % chunk || d.n_rows * d.tokens_per_row < 16384 || d.bpt * 4 > 64) return 0;   // (a batch's ids: 4 tokens x bpt lanes)
     const size_t budget = 144 * 1024;
     if ((size_t)d.byte_rows * chunk * esize > budget) return 0;
     return chunk;   // one chunk per slice: the most slices, the smallest table image
