@@ -57,21 +57,29 @@ __global__ __launch_bounds__(kThreads) void rows_rmsnorm_w_kernel(const IdT *__r
 
 // The attention core.  Workgroup = (head h, tile of TT tokens); K_h and V_h of all character rows live in LDS for the whole
 // tile (132 x 64 x 2 floats = 68 KB at head_dim 64: two workgroups per CU); one wave per token.
-//   scores: lane = key (window * c_v <= 64 of them): 64 fmas of the lane's key row (LDS, padded rows) with q handed out lane by lane
-//   softmax: two wave reductions
-//   y:      lane = element of the head (HD / 64 per lane): a loop over the keys, p and the key's character id handed out by readlane
+//   scores: lane = key (window * c_v <= 64 of them).  The query row's address is wave-uniform, so q arrives through the scalar
+//           cache into SGPRs and every product is ONE v_fmac (SGPR x the lane's key element from LDS): no cross-lane traffic.
+//   softmax: two wave reductions; p and the key's character id go to a per-wave LDS strip as (p, id) pairs.
+//   y:      lane = (key group g, four consecutive elements of the head): 64 / (HD / 4) groups walk the keys g, g + groups, ...,
+//           one 8-byte LDS read for (p, id) and one 16-byte read of the value row piece per key, four fmas; the groups' partial
+//           sums meet through two (one at head_dim 128) cross-lane exchanges.  (The first version handed p and id out with two
+//           readlanes per key and element-per-lane value reads: 4.7 ms per 65 536 tokens x 32 heads.)
+constexpr int kSwaThreads = 512, kSwaWaves = kSwaThreads / 64;   // 8 waves share one copy of K_h / V_h: two workgroups = 16 waves per CU
+
 template <int HDL>   // head_dim = 64 * HDL
-__global__ __launch_bounds__(kThreads) void char_swa_kernel(const float *__restrict__ q, const float *__restrict__ ktab, const float *__restrict__ vtab,
+__global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__restrict__ q, const float *__restrict__ ktab, const float *__restrict__ vtab,
                                                             const int64_t *__restrict__ char_ids, int64_t n0, int64_t n_tok, int64_t T, int c_v, int window,
                                                             int char_rows, int n_heads, int tile_tokens, float *__restrict__ y, uint32_t *status) {
     constexpr int HD = 64 * HDL, KS = HD + 4;                    // key rows padded by 16 bytes: lanes reading different rows spread over the banks
+    constexpr int QUADS = HD / 4, GROUPS = 64 / QUADS;           // 16 x 4 at head_dim 64, 32 x 2 at 128
     extern __shared__ __attribute__((aligned(16))) float lds_kv[];
     float *lk = lds_kv, *lv = lds_kv + (size_t)char_rows * KS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float2 *pid = (float2 *)(lv + (size_t)char_rows * HD) + wave * 64;   // this wave's (p, id) strip
     const int h = blockIdx.y;
     const int HDIM = n_heads * HD;
-    for (int i = tid; i < char_rows * (HD / 4); i += kThreads) {
+    for (int i = tid; i < char_rows * (HD / 4); i += kSwaThreads) {
         const int r = i / (HD / 4), c = (i - r * (HD / 4)) * 4;
         *(float4v *)(lk + r * KS + c) = *(const float4v *)(ktab + (int64_t)r * HDIM + h * HD + c);
         *(float4v *)(lv + r * HD + c) = *(const float4v *)(vtab + (int64_t)r * HDIM + h * HD + c);
@@ -80,53 +88,60 @@ __global__ __launch_bounds__(kThreads) void char_swa_kernel(const float *__restr
     const int nkeys = window * c_v;
     const int w = lane / c_v, c = lane - w * c_v;                 // this lane's key: window slot w (0 = oldest), character slot c
     const float scale = 1.0f / sqrtf((float)HD);                 // qk / self.head_dim ** .5, line 220
+    const int g = lane / QUADS, dq = lane - g * QUADS;            // value pass: key group, element quad
     const int64_t t_lo = (int64_t)blockIdx.x * tile_tokens, t_hi = min(n_tok, t_lo + tile_tokens);
-    for (int64_t tl = t_lo + wave; tl < t_hi; tl += kWaves) {
-        const int64_t n = n0 + tl;                               // flat token index; the window may not leave the token's batch row
-        const int64_t tr = n % T;
-        const int64_t src_t = tr - (window - 1) + w;
-        const bool is_key = lane < nkeys, real = is_key && src_t >= 0;   // src_t < 0: a zero vector of the padding (lines 175-176)
+    // the character id of this lane's key for token tl (-1: a padding key or no key): requested one token ahead of its use
+    auto key_id = [&](int64_t tl) -> int64_t {
+        const int64_t n = n0 + tl, tr = n % T, src_t = tr - (window - 1) + w;   // the window may not leave the token's batch row
+        return (tl < t_hi && lane < nkeys && src_t >= 0) ? char_ids[(n - tr + src_t) * c_v + c] : -1;
+    };
+    int64_t id_nx = key_id(t_lo + wave);
+    for (int64_t tl = t_lo + wave; tl < t_hi; tl += kSwaWaves) {
+        const int64_t idq = id_nx;
+        id_nx = key_id(tl + kSwaWaves);
+        const bool is_key = lane < nkeys, real = idq >= 0;       // not real: a zero vector of the padding (lines 175-176)
         int id = 0;
         if (real) {
-            const int64_t v = char_ids[(n - tr + src_t) * c_v + c];
-            id = (int)v;
-            if ((uint64_t)v >= (uint64_t)char_rows) { if (status) atomicOr(status, kStatusByteOor); id = 0; }
+            id = (int)idq;
+            if ((uint64_t)idq >= (uint64_t)char_rows) { if (status) atomicOr(status, kStatusByteOor); id = 0; }
         }
-        float qv[HDL];
-#pragma unroll
-        for (int g = 0; g < HDL; ++g) qv[g] = q[tl * HDIM + h * HD + lane + 64 * g];
-        // ---- scores
-        float s = 0.f;
+        // ---- scores: q[tl, h, :] is addressed with scalars only
+        const float *qrow = q + tl * HDIM + h * HD;
         const float *krow = lk + id * KS;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;           // four chains: a single one is 64 dependent fmas deep
 #pragma unroll
-        for (int g = 0; g < HDL; ++g) {
-#pragma unroll
-            for (int d4 = 0; d4 < 16; ++d4) {
-                const float4v kk = *(const float4v *)(krow + 64 * g + 4 * d4);
-                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 0)) * kk.x;
-                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 1)) * kk.y;
-                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 2)) * kk.z;
-                s += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qv[g]), 4 * d4 + 3)) * kk.w;
-            }
+        for (int d4 = 0; d4 < HD / 4; ++d4) {
+            const float4v kk = *(const float4v *)(krow + 4 * d4);
+            s0 += qrow[4 * d4 + 0] * kk.x;
+            s1 += qrow[4 * d4 + 1] * kk.y;
+            s2 += qrow[4 * d4 + 2] * kk.z;
+            s3 += qrow[4 * d4 + 3] * kk.w;
         }
-        s = real ? s * scale : 0.f;
+        const float s = real ? ((s0 + s1) + (s2 + s3)) * scale : 0.f;
         // ---- softmax over the nkeys keys (padding keys included, score 0)
         const float m = wave_max(is_key ? s : -INFINITY);
         const float e = is_key ? expf(s - m) : 0.f;
         const float p = e / wave_sum(e);
-        const float pv = real ? p : 0.f;                         // a padding key's value is the zero vector
-        // ---- y = sum_j p_j v_j, lane = element
-        float acc[HDL];
-#pragma unroll
-        for (int g = 0; g < HDL; ++g) acc[g] = 0.f;
-        for (int j = 0; j < nkeys; ++j) {
-            const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pv), j));
-            const int idj = __builtin_amdgcn_readlane(id, j);
-#pragma unroll
-            for (int g = 0; g < HDL; ++g) acc[g] += pj * lv[idj * HD + lane + 64 * g];
+        pid[lane] = float2{real ? p : 0.f, __int_as_float(id)};  // a padding key's value is the zero vector; lanes past the keys: p = 0
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- y = sum_j p_j v_j
+        float4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int j = g; j < 64; j += GROUPS) {
+            const float2 pi = pid[j];
+            const float4v vv = *(const float4v *)(lv + __float_as_int(pi.y) * HD + 4 * dq);
+            acc += pi.x * vv;
         }
 #pragma unroll
-        for (int g = 0; g < HDL; ++g) y[tl * HDIM + h * HD + lane + 64 * g] = acc[g];
+        for (int o = QUADS; o < 64; o <<= 1) {
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (lane < QUADS) *(float4v *)(y + tl * HDIM + h * HD + 4 * dq) = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is rewritten for the wave's next token
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -162,7 +177,7 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
     if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
     if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wk, d.dim, d.dim, hdim, kt, hdim, true, stream))) return rc;
     if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wv, d.dim, d.dim, hdim, vt, hdim, true, stream))) return rc;
-    const size_t lds = ((size_t)d.char_rows * (d.head_dim + 4) + (size_t)d.char_rows * d.head_dim) * sizeof(float);
+    const size_t lds = ((size_t)d.char_rows * (d.head_dim + 4) + (size_t)d.char_rows * d.head_dim + 2 * 64 * kSwaWaves) * sizeof(float);
     if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "char_swa: %d character rows x head_dim %d need %zu B of LDS (> 160 KiB)", d.char_rows, d.head_dim, lds);
     for (int64_t n0 = 0; n0 < N; n0 += slab) {
         const int64_t nn = N - n0 < slab ? N - n0 : slab;
@@ -173,17 +188,17 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
         if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
         if ((rc = launch_gemm_rows(xn, d.dim, nn, (const float *)d.wq, d.dim, d.dim, hdim, qb, hdim, true, stream))) return rc;
         // ---- attention
-        const int tile = 128;
+        const int tile = 256;
         const dim3 grid((unsigned)((nn + tile - 1) / tile), (unsigned)d.n_heads);
         if (d.head_dim == 64) {
             static std::atomic<uint64_t> lds_ok{0};
             if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<1>, lds_ok, "char_swa_kernel"))) return rc;
-            hipLaunchKernelGGL(char_swa_kernel<1>, grid, dim3(kThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
+            hipLaunchKernelGGL(char_swa_kernel<1>, grid, dim3(kSwaThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
                                d.char_rows, d.n_heads, tile, yb, d.status);
         } else {
             static std::atomic<uint64_t> lds_ok{0};
             if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<2>, lds_ok, "char_swa_kernel"))) return rc;
-            hipLaunchKernelGGL(char_swa_kernel<2>, grid, dim3(kThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
+            hipLaunchKernelGGL(char_swa_kernel<2>, grid, dim3(kSwaThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
                                d.char_rows, d.n_heads, tile, yb, d.status);
         }
         if ((rc = check_launch("char_swa_kernel"))) return rc;
