@@ -502,15 +502,23 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
     tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
     tok = tok if tok.is_contiguous() else tok.contiguous()
     f32 = torch.float32
-    tt, bt = _contig(tok_table.detach(), f32, "tok_table"), _contig(byte_table.detach(), f32, "byte_table")
+    # bf16 tables (the production cast, train_gpt.py:1124-1126): the kernels of this mixin are fp32, so the operands are widened
+    # once per call -- the tables as they are (bf16 values), the fp32 master weights rounded to bf16 first, as
+    # `self.q_w.type_as(x)` does (lines 277-278, 185-186) -- and the result is rounded once to bf16 by the caller
+    bf = tok_table.dtype == torch.bfloat16
+    if byte_table.dtype != tok_table.dtype:
+        raise TypeError(f"cross_attn: byte table is {byte_table.dtype} but the token table is {tok_table.dtype}")
+    wide = (lambda t: t.detach().float()) if bf else (lambda t: t.detach())
+    as_used = (lambda w: w.detach().to(torch.bfloat16).float()) if bf else (lambda w: w.detach())
+    tt, bt = _contig(wide(tok_table), f32, "tok_table"), _contig(wide(byte_table), f32, "byte_table")
     D = tt.shape[1]
     if bt.shape[1] != D:
         raise AssertionError("cross_attn: byte_dim == token_dim == model_dim (train_gpt.py:449)")
     HD = n_heads * 128
-    qw, kvw, pw = _contig(q_w.detach(), f32, "q_w"), _contig(kv_w.detach(), f32, "kv_w"), _contig(proj_w.detach(), f32, "proj_w")
+    qw, kvw, pw = _contig(as_used(q_w), f32, "q_w"), _contig(as_used(kv_w), f32, "kv_w"), _contig(as_used(proj_w), f32, "proj_w")
     if qw.shape != (HD, D) or kvw.shape != (2, HD, D) or pw.shape != (D, HD):
         raise AssertionError(f"cross_attn: weights {tuple(qw.shape)}, {tuple(kvw.shape)}, {tuple(pw.shape)} do not fit heads={n_heads}, dim={D}")
-    lam = _contig(lambda_factor.detach().reshape(1), f32, "lambda_factor")
+    lam = _contig(as_used(lambda_factor).reshape(1), f32, "lambda_factor")
     ia = _contig(ids_a.reshape(-1), torch.int64, "ids_a")
     ib = None if ids_b is None else _contig(ids_b.reshape(-1), torch.int64, "ids_b")
     if ia.numel() != T * bpt or (ib is not None and ib.numel() != T * bpt):
@@ -543,15 +551,17 @@ class _CrossAttnFn(torch.autograd.Function):
         saved = torch.empty(2 * tokens.shape[-1] * kw["n_heads"] * 128, dtype=torch.float32, device=tok_table.device)
         ctx.save_for_backward(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, saved, *rot)
         ctx.kw = kw
-        return _cross_attn_fwd(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, *rot, saved_qy=saved, **kw)
+        x = _cross_attn_fwd(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, *rot, saved_qy=saved, **kw)
+        return x.to(tok_table.dtype)
 
     @staticmethod
     def backward(ctx, gx):
         tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, saved, cq, sq, ck, sk = ctx.saved_tensors
         g = cross_attn_backward(gx, tokens, ids_a, tok_table, byte_table, q_w=q_w, kv_w=kv_w, proj_w=proj_w, lambda_factor=lambda_factor,
                                 cos_q=cq, sin_q=sq, cos_k=ck, sin_k=sk, saved_qy=saved, **ctx.kw)
-        return (g["tok_table"], g["byte_table"], g["q_w"], g["kv_w"], g["proj_w"], g["lambda_factor"].reshape(lambda_factor.shape),
-                None, None, None, None)
+        # fp32 sums; the tables' gradients are rounded once to the tables' dtype (bf16 in production), the weights stay fp32 masters
+        return (g["tok_table"].to(tok_table.dtype), g["byte_table"].to(byte_table.dtype), g["q_w"], g["kv_w"], g["proj_w"],
+                g["lambda_factor"].reshape(lambda_factor.shape).to(lambda_factor.dtype), None, None, None, None)
 
 
 @torch.compiler.disable
@@ -563,7 +573,7 @@ def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, 
         tokens = tokens[None]
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, None, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
                                           bpt, n_heads, norm_tok, norm_byte, head_layout, eps)
-    g = _contig(grad_out.reshape(T, D), torch.float32, "grad_out")
+    g = _contig(grad_out.reshape(T, D).float(), torch.float32, "grad_out")
     out = {"tok_table": torch.zeros_like(keep[1]), "byte_table": torch.zeros_like(keep[2]), "q_w": torch.zeros_like(keep[3]),
            "kv_w": torch.zeros_like(keep[4]), "proj_w": torch.zeros_like(keep[5]), "lambda_factor": torch.zeros(1, dtype=torch.float32, device=dev)}
     gr = capi.MotCrossAttnGrads()
@@ -615,7 +625,8 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
     tokens (1, T) -> (1, T, dim).  The reference asserts batch 1 (line 275).  fp32.  With autograd enabled and
     differentiable parameters it records one backward node (one id tensor; the two-id-tensor embedding is forward-only).
     head_layout "as_viewed" reproduces the reference's reshape of k and v (lines 283-284); "per_token" is the
-    rearrange its comment names."""
+    rearrange its comment names.  bfloat16 tables are accepted (operands widened once per call, fp32 arithmetic, bf16 result and
+    table gradients)."""
     if tokens.ndim == 1:
         tokens = tokens[None]
     assert tokens.shape[0] == 1, "Must use batch size = 1 for FlexAttention"      # train_gpt.py:275
@@ -629,7 +640,7 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
     # `kv_cache` (a dict the caller keeps, e.g. on the module): inference calls reuse the per-byte-row K/V tables while the
     # byte table, kv_w and lambda_factor are unchanged (tensor versions are checked)
     return _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                           kv_cache=kv_cache, **kw)
+                           kv_cache=kv_cache, **kw).to(tok_table.dtype)
 
 
 _SWA_VERSIONS = {"no_residual": capi.SWA_NO_RESIDUAL, "one_residual": capi.SWA_ONE_RESIDUAL, "two_residual": capi.SWA_TWO_RESIDUAL}
