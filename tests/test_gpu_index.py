@@ -162,3 +162,67 @@ def test_full_size_c4(dc):
     assert int((padded == gi.PAD).sum()) == stats[1] and int((pulled == gi.PAD).sum()) == stats[2]
     mean_valid = float(nv_p.float().mean())
     assert 3.4 <= mean_valid <= 5.4, mean_valid                      # 4.4 +- 1 chars/token
+
+
+# ------------------------------------------------------------------------------------------------
+# The byte-index work INSIDE the fused forward (mot_wave.hpp, round 2): every wave produces the ids of its own unit of 16 or 32
+# tokens from a 64-token window, with no workgroup barrier.  Same cases as the standalone kernels above, through
+# embed_mix(..., return_ids=True): padded and pulled ids bit-exact against the oracle, for both unit sizes (the launcher takes
+# 32-token units from 131 072 tokens on), both pull directions and no pull, int16 and int32 tables, rows that cannot be read
+# with 16-byte vectors (bpt 3, 20), windows that must walk outwards for their halo.
+# ------------------------------------------------------------------------------------------------
+def _fused_ids(toks, tab, bpt, pull, add_padded=False):
+    import mixture_of_tokenizers_amd as mot
+    Db = 4
+    Et = torch.zeros((int(tab.shape[0]), bpt * Db), device=DEV)
+    Eb = torch.zeros((gi.BYTE_VOCAB, Db), device=DEV)
+    r = mot.embed_mix(dev(toks), Et, Eb, mode="sum", bpt=bpt, ttb=dev(tab), pull=pull, add_padded=add_padded, return_ids=True)
+    mot.check_status()
+    return host(r.ids_padded), host(r.ids_pulled)
+
+
+@pytest.mark.parametrize("bpt,B,T,vocab,seed,eot_p", [
+    (16, 8, 2048, 512, 7101, 1 / 700),     # 16 384 tokens: 16-token units
+    (16, 64, 2048, 512, 7102, 1 / 700),    # 131 072 tokens: 32-token units
+    (16, 3, 1000, 512, 7103, 0.02),        # ragged last unit (1000 = 62 * 16 + 8)
+    (8, 5, 777, 97, 7104, 0.0),            # no EOT anywhere; rows of one 16-byte vector
+    (32, 2, 513, 512, 7105, 0.3),          # EOT-dense; rows of four vectors (two cached, two re-read)
+    (3, 8, 33, 64, 7106, 0.1),             # mathblations-sized slots: element loads; rows shorter than a window
+    (64, 2, 130, 512, 7107, 0.05),         # MOT_MAX_BPT
+    (20, 4, 300, 512, 7108, 0.01),         # 40-byte rows: element loads
+    (16, 1, 1, 64, 7109, 0.0),             # a single token
+    (16, 2, 17, 64, 7110, 0.2),
+])
+def test_fused_ids_vs_oracle(bpt, B, T, vocab, seed, eot_p):
+    toks = gi.edge_tokens(seed, B, T, vocab, eot_p=eot_p)
+    if eot_p == 0.0:
+        toks[toks == vocab - 1] = 2
+    for side, pull in (("left", "left"), ("right", "right"), ("left", None)):
+        tab = gi.synth_ttb(seed + 1, vocab, bpt, side, mean_valid=min(4.4, bpt / 2))
+        padded_ref = orc.tokens_to_bytes(toks, tab.astype(np.float32))
+        pulled_ref = {"left": orc.pull_from_left, "right": orc.pull_from_right}[pull](padded_ref, bpt, gi.PAD, gi.EOT) if pull else padded_ref
+        for t_ in (tab, tab.astype(np.int32)):
+            padded, pulled = _fused_ids(toks, t_, bpt, pull, add_padded=(seed % 2 == 0))
+            np.testing.assert_array_equal(padded, padded_ref)
+            np.testing.assert_array_equal(pulled, pulled_ref)
+
+
+@pytest.mark.parametrize("B,T", [(3, 1500), (90, 1500)])   # 16-token and 32-token units
+def test_fused_ids_long_lookback(B, T):
+    """Hundreds of consecutive empty tokens: a window's built-in halo (48 or 32 tokens) holds no byte, so the wave walks outwards,
+    64 tokens per step, across many steps -- in both directions -- and stops at an EOT token or the row's end."""
+    bpt, vocab = 16, 64
+    tab = gi.synth_ttb(42, vocab, bpt, "left")
+    tabr = gi.to_right_pad(tab)
+    toks = np.zeros((B, T), dtype=np.int32)            # id 0 = no valid byte
+    toks[0, 5] = 7; toks[0, 700] = 9; toks[0, 1499] = 11
+    toks[1, 0] = 5; toks[1, 1] = vocab - 1; toks[1, 1400] = 6
+    rs = np.random.RandomState(4)
+    for b in range(3, B):                               # sparse rows: a byte-carrying token every ~200 positions, an EOT now and then
+        at = rs.choice(T, 8, replace=False)
+        toks[b, at] = rs.randint(1, vocab, 8)
+    for t_, pull, fn in ((tab, "left", orc.pull_from_left), (tabr, "right", orc.pull_from_right)):
+        ref = orc.tokens_to_bytes(toks, t_.astype(np.float32))
+        padded, pulled = _fused_ids(toks, t_, bpt, pull)
+        np.testing.assert_array_equal(padded, ref)
+        np.testing.assert_array_equal(pulled, fn(ref, bpt, gi.PAD, gi.EOT))
