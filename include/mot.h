@@ -165,6 +165,7 @@ int mot_gather_rows(const void *ids_a, const void *ids_b, int ids_elem_bytes, in
 #define MOT_FLAG_LINEAR_ONE_LAUNCH 1u /* CONCAT_LINEAR: the one-launch tile kernel instead of the composed kernels       */
 #define MOT_FLAG_MEAN_GENERIC 2u      /* MEAN: the whole-row kernel even where the LDS column-slice kernel qualifies     */
 #define MOT_FLAG_BWD_DU_FP32 4u       /* CONCAT_LINEAR backward, bf16: du = dy.W on the fp32 MFMA instead of the bf16 one */
+#define MOT_FLAG_LINEAR_COMPOSED 8u   /* CONCAT_LINEAR, bf16: the multi-kernel path even where the one gather-GEMM qualifies */
 
 typedef struct MotEmbedMixDesc {
     uint32_t struct_size; /* sizeof(MotEmbedMixDesc), checked */
@@ -257,8 +258,10 @@ int mot_embed_mix_bwd(const MotEmbedMixDesc *fwd /* host */, const MotEmbedMixGr
 
 /*
  * CONCAT_LINEAR runs as several kernels inside one call (index kernels when the ids come from the ttb, a gather that
- * writes the concat operand into the workspace, a dense MFMA kernel, a row-norm pass); MOT_FLAG_LINEAR_ONE_LAUNCH in
- * desc->flags selects the one-launch tile kernel instead.  Same results to the parity bar; the workspace size differs,
+ * writes the concat operand into the workspace, a dense MFMA kernel, a row-norm pass); in bf16, with one id tensor, embedding
+ * dims that are multiples of 8, a concat width that is a multiple of 32 and model_dim 256/512/768/1024, everything behind the
+ * index kernels is ONE gather-GEMM kernel (MOT_FLAG_LINEAR_COMPOSED keeps the separate kernels).  MOT_FLAG_LINEAR_ONE_LAUNCH in
+ * desc->flags selects the older one-launch tile kernel instead.  Same results to the parity bar; the workspace size differs,
  * so mot_embed_mix_workspace_bytes must see the same flags as the call.
  */
 size_t mot_embed_mix_desc_size(void); /* sizeof(MotEmbedMixDesc) in this build, for bindings */

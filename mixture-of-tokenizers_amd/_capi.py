@@ -24,7 +24,7 @@ IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32, BF16 = 0, 1
 MAX_BPT = 64
 ABI_VERSION = 9
-FLAG_LINEAR_ONE_LAUNCH, FLAG_MEAN_GENERIC, FLAG_BWD_DU_FP32 = 1, 2, 4
+FLAG_LINEAR_ONE_LAUNCH, FLAG_MEAN_GENERIC, FLAG_BWD_DU_FP32, FLAG_LINEAR_COMPOSED = 1, 2, 4, 8
 HEADS_AS_VIEWED, HEADS_PER_TOKEN = 0, 1
 
 

@@ -46,7 +46,7 @@ static int validate_embed_mix(const MotEmbedMixDesc *d) {
     if (d->struct_size != sizeof(MotEmbedMixDesc))
         return set_error(MOT_EINVAL, "embed_mix: struct_size %u != %zu (ABI mismatch)", d->struct_size, sizeof(MotEmbedMixDesc));
     if (d->dtype != MOT_F32 && d->dtype != MOT_BF16) return set_error(MOT_EINVAL, "embed_mix: bad dtype %d", d->dtype);
-    if ((d->flags & ~(MOT_FLAG_LINEAR_ONE_LAUNCH | MOT_FLAG_MEAN_GENERIC | MOT_FLAG_BWD_DU_FP32)) || d->reserved0)
+    if ((d->flags & ~(MOT_FLAG_LINEAR_ONE_LAUNCH | MOT_FLAG_MEAN_GENERIC | MOT_FLAG_BWD_DU_FP32 | MOT_FLAG_LINEAR_COMPOSED)) || d->reserved0)
         return set_error(MOT_EINVAL, "embed_mix: unknown flags 0x%x / reserved0 %u", d->flags, d->reserved0);
     if (d->n_rows < 0 || d->tokens_per_row < 0) return set_error(MOT_ESHAPE, "embed_mix: negative shape");
     if (d->mode < MOT_MIX_NOOP || d->mode > MOT_MIX_CONCAT_LINEAR) return set_error(MOT_EINVAL, "embed_mix: bad mode %d", d->mode);

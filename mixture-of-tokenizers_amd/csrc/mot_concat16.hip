@@ -1,0 +1,382 @@
+// mot_concat16.hip -- the concat + linear mixin in the production dtype as ONE dense-MFMA kernel (gfx950):
+//     x = rms_norm?( bf16( W . cat(norm?(E_t[tok]), norm?(E_b[id_0]), ..., norm?(E_b[id_{bpt-1}])) + bias ) )
+// (ByteMixinConcat on FlexibleEmbedding's outputs, scaled-pre-train/train_gpt.py:342-379, 430-443, CastedLinear 185-186;
+//  DigitMixinConcat, mathblations/model.py:256-268), bf16 tables / weight / output, fp32 accumulation.
+//
+// The composed path (index kernels -> concat_rows_kernel -> gemm_rows_bf16_kernel -> rows_rms_inplace_kernel) spends 40 % of
+// its time outside the contraction and runs the contraction itself at 23 % of the bf16 MFMA peak: 128 x 128 blocks read one
+// 16-byte LDS fragment per MFMA, and the concat operand makes two trips through HBM.  Here
+//   * a workgroup owns WHOLE output rows (64 MT tokens x all Dm = 128 NT columns; 8 waves as 2 x 4, a wave 32 MT x 32 NT), so
+//     the row norm is an epilogue (per-row sum of squares across the four column waves through LDS), and a fragment feeds
+//     MT or NT MFMAs;
+//   * the A operand is GATHERED: per 32-deep step a thread fetches one 16-byte piece of a token row or byte row, scales it by
+//     the row's rms factor, rounds to bf16 (the reference's rounding point: norm() returns a bf16 tensor) and writes it into the
+//     step's LDS tile -- the concat tensor never exists;
+//   * W is staged by LDS-DMA (global_load_lds, 16 bytes per lane, no staging registers), XOR-swizzled on the SOURCE side so that
+//     the lane-linear LDS image reads back without bank conflicts: piece p of row n sits at n * 64 + ((p ^ (n >> 2)) & 3) * 16;
+//   * the output tile leaves through LDS as whole 16-byte pieces (the composed kernel's 2-byte lane stores were a measurable part
+//     of its epilogue).
+// One barrier per step; the DMA of step s + 1 and the gathered pieces of step s + 1 are in flight while step s multiplies.
+#include "mot_mix.hpp"
+#include <type_traits>
+
+namespace mot {
+
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+typedef float f32x16c __attribute__((ext_vector_type(16)));
+
+struct C16Args {
+    const int32_t *tokens;     // [n]
+    const int64_t *ids;        // [n, bpt]
+    int64_t n;
+    const __bf16 *tok_table; int64_t tok_rows; int Dt;
+    const __bf16 *byte_table; int64_t byte_rows; int Db; int bpt;
+    int norm_tok;              // token rows are rms-normalised (factor computed per tile, below)
+    const float *byte_rnorm;   // [byte_rows] rms factors of the byte table, or null (no byte norm)
+    const __bf16 *W;           // [Dm, K]
+    const __bf16 *bias;        // [Dm] or null
+    int K, Dm, tok_lo, byte_lo;
+    int norm_out;
+    float eps;
+    __bf16 *out;               // [n, Dm]
+    float *row_rnorm;          // optional [n]
+    uint32_t *status;
+};
+
+constexpr int kC16Threads = 512;
+typedef int i32x4c __attribute__((ext_vector_type(4)));
+
+// LDS reads the COMPILER must not see.  hipcc orders every LDS read it emits behind every LDS-DMA still in flight (it cannot
+// tell which bytes the DMA writes), i.e. s_waitcnt vmcnt(0) in front of the first ds_read after a global_load_lds -- which
+// would serialise the DMA of step s + 2 with the multiplies of step s.  The reads of the loop are therefore inline asm, ordered
+// against the DMA by hand: a stage is read only after the barrier behind the wait that retired it (see the loop).
+#define C16_FRAG(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+__device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)p; }
+__device__ __forceinline__ uint32_t lds_u16_now(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ float lds_f32_now(uint32_t addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// workgroup barrier that waits for this wave's LDS traffic only (no vmcnt drain: the DMA and the gathered pieces stay in flight)
+__device__ __forceinline__ void c16_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// NS stages of W in LDS (NS - 1 steps of DMA in flight), ONE stage of the gathered operand (its next step waits in registers)
+template <int MT, int NT, int NS>
+__global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Args P) {
+    constexpr int BM = 64 * MT, BN = 128 * NT, WMR = 32 * MT, WNR = 32 * NT, PD = NS - 1;
+    constexpr int kStageB = BN * 64, kStageA = BM * 64, kDma = BN * 4 / kC16Threads;
+    static_assert(PD == 1 || PD == 2, "one or two steps ahead");
+    extern __shared__ __attribute__((aligned(16))) char lds_c[];
+    char *sA = lds_c + NS * kStageB;
+    uint16_t *sIds = (uint16_t *)(sA + kStageA);                                  // [BM * bpt]
+    float *sRn = (float *)(lds_c + NS * kStageB + kStageA + ((BM * P.bpt * 2 + 15) & ~15));   // [byte_rows] rms factors of the byte rows (1 when that part is not normalised)
+    const uint32_t oB = lds_off(lds_c), oA = lds_off(sA), oIds = lds_off(sIds), oRn = lds_off(sRn);
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 2) * WMR, wn = (wave & 3) * WNR;
+    const int64_t j0 = (int64_t)blockIdx.x * BM;
+    const int nrows = (int)min((int64_t)BM, P.n - j0);
+    const int K = P.K, bpt = P.bpt;
+    // ---- W by LDS-DMA: wave-instruction j = i * 8 + wave writes 1 KiB = stage rows 16 j .. 16 j + 15, lane -> (row, physical piece).
+    // Stage row q of a wave's strip holds W row strip + (q % 32) * NT + q / 32: MFMA column li of tile b is output column
+    // li * NT + b, so that a lane ends up with NT CONSECUTIVE outputs of a row (packed stores in the epilogue).
+    uint32_t goff[kDma];   // byte offset into W of this lane's piece of step 0, per DMA instruction
+#pragma unroll
+    for (int i = 0; i < kDma; ++i) {
+        const int q = (i * 8 + wave) * 16 + (lane >> 2), strip = q / WNR, within = q - strip * WNR;
+        const int nrow = strip * WNR + (within & 31) * NT + (within >> 5);
+        goff[i] = (uint32_t)(nrow * K + 8 * (((lane & 3) ^ (q >> 2)) & 3)) * 2u;
+    }
+    const int nsteps = K / 32;
+    auto b_request = [&](int s) {   // (a step past the end re-reads the last one into a stage nobody reads: the loop stays branch-free)
+        char *sB = lds_c + (s % NS) * kStageB;
+        const uint32_t ko = 64u * (uint32_t)min(s, nsteps - 1);
+#pragma unroll
+        for (int i = 0; i < kDma; ++i) {
+            const char *g = (const char *)P.W + (goff[i] + ko);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(sB + (i * 8 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    b_request(0);
+    if (PD == 2) b_request(1);
+    // ---- ids of the tile's tokens -> LDS (clamped; rows past the batch repeat the last valid token: computed, never stored)
+    for (int i0 = tid; i0 < BM * bpt; i0 += 4 * kC16Threads) {   // four loads in flight per thread
+        int64_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * kC16Threads, BM * bpt - 1);
+            v[u] = P.ids[(j0 + min(i / bpt, nrows - 1)) * bpt + i % bpt];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kC16Threads;
+            if ((uint64_t)v[u] >= (uint64_t)P.byte_rows) { if (P.status) atomicOr(P.status, kStatusByteOor); v[u] = 0; }
+            if (i < BM * bpt) sIds[i] = (uint16_t)v[u];
+        }
+    }
+    for (int i = tid; i < (int)P.byte_rows; i += kC16Threads) sRn[i] = P.byte_rnorm ? P.byte_rnorm[i] : 1.f;
+    // ---- this thread's piece of the gathered operand: row arow, logical 16-byte piece apiece of every 64-byte step row
+    const bool a_thread = tid < BM * 4;   // (whole waves: BM * 4 is a multiple of 64)
+    const int arow = tid >> 2, apiece = tid & 3;
+    int tok = 0;
+    float rn_tok = 1.f;
+    if (a_thread) {
+        tok = P.tokens[j0 + min(arow, nrows - 1)];
+        if ((uint64_t)(uint32_t)tok >= (uint64_t)P.tok_rows) { if (P.status) atomicOr(P.status, kStatusTokenOor); tok = 0; }
+    }
+    const __bf16 *trow = P.tok_table + (int64_t)tok * P.Dt;
+    if (P.norm_tok) {   // the four threads of a row share its sum of squares (the row comes back out of L2 in the steps below)
+        float ss = 0.f;
+        if (a_thread)
+            for (int p0 = apiece; p0 < P.Dt / 8; p0 += 32) {   // eight loads in flight
+                bf16x8c v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *(const bf16x8c *)(trow + 8 * min(p0 + 4 * u, P.Dt / 8 - 1));
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (p0 + 4 * u < P.Dt / 8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss += (float)v[u][e] * (float)v[u][e];
+                    }
+            }
+        ss += __shfl_xor(ss, 1, 64);
+        ss += __shfl_xor(ss, 2, 64);
+        rn_tok = rms_scale(ss, P.Dt, P.eps);
+    }
+    const uint32_t a_dst = oA + arow * 64 + ((apiece ^ (arow >> 2)) & 3) * 16;
+    // the walk over this thread's pieces: k = 8 apiece, + 32 per step; inside the byte part (slot, within) advance with it.
+    // Branch-free (and one global load per request whatever the part) so that hipcc can COUNT the loads in flight at the commit.
+    int ak = 8 * apiece, slot = 0, within = 0;
+    {   // the first of them inside the byte part
+        const int d = P.Dt - 8 * apiece;
+        const int first = P.byte_lo == 0 ? 8 * apiece : (d > 0 ? (d + 31) / 32 : 0) * 32 - d;
+        slot = first / P.Db; within = first - slot * P.Db;
+    }
+    const int dslot = 32 / P.Db, dwithin = 32 - dslot * P.Db;
+    __syncthreads();   // sIds, sRn  (hipcc drains the DMA of the first stages here: once per tile)
+    auto a_request = [&](i32x4c &raw, float &scale) {
+        const int kt = ak - P.tok_lo;
+        const bool in_tok = (unsigned)kt < (unsigned)P.Dt;
+        const int sl = min(slot, bpt - 1);   // (requests past the last step read a valid row and are never used)
+        const int id = (int)lds_u16_now(oIds + (arow * bpt + sl) * 2);
+        const float rb = lds_f32_now(oRn + id * 4);
+        const __bf16 *src = in_tok ? trow + kt : P.byte_table + (int64_t)id * P.Db + within;
+        // (asm: hipcc answers a plain load among LDS-DMA with vmcnt(0) at its use; the commit below counts instead.  The registers
+        //  stay pending until that wait: nothing else may touch them -- they are outputs here and operands of the wait only)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(raw) : "v"(src) : "memory");
+        scale = in_tok ? rn_tok : rb;
+        int w2 = within + dwithin, s2 = slot + dslot;
+        if (w2 >= P.Db) { w2 -= P.Db; ++s2; }
+        within = in_tok ? within : w2;
+        slot = in_tok ? slot : s2;
+        ak += 32;
+    };
+    // scale in fp32, round once to bf16 (the reference's norm() output), into the step's tile.  INFLIGHT = vector-memory operations
+    // requested after this piece AND after the DMA of the same step that may stay in flight (loads retire in order)
+    auto a_commit = [&](i32x4c &raw_bits, float scale, auto inflight) {
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw_bits) : "n"(decltype(inflight)::value) : "memory");
+        const bf16x8c raw = __builtin_bit_cast(bf16x8c, raw_bits);
+        bf16x8c v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)((float)raw[e] * scale);
+        *(__attribute__((address_space(3))) bf16x8c *)(uintptr_t)a_dst = v;
+    };
+    f32x16c acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // fragment addresses: row = (wm | wn) + 32 t + li, piece (2 kk + h) ^ (row >> 2): the tile index t only adds t * 2048, kk flips bit 5
+    const uint32_t fa0 = oA + (wm + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
+    const uint32_t fb0 = (wn + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
+    i32x4c r0_raw = {0, 0, 0, 0}, r1_raw = {0, 0, 0, 0};
+    float r0_scale = 1.f, r1_scale = 1.f;
+    constexpr bool kAllGather = BM * 4 == kC16Threads;   // every thread carries a piece: no branch around the requests
+    constexpr int kInflight = PD == 2 ? kDma + 1 : 0;
+    if (kAllGather || a_thread) {
+        a_request(r0_raw, r0_scale);
+        if (PD == 2) a_request(r1_raw, r1_scale);
+        a_commit(r0_raw, r0_scale, std::integral_constant<int, PD - 1>{});
+    }
+    // step s: [barrier: stage s of W and the gathered tile s are in LDS for everyone] request W step s + PD (DMA) and piece s + PD
+    // (registers), multiply step s, [barrier: everyone has read the gathered tile], commit piece s + 1 -- which waits for that piece
+    // with a COUNTED vmcnt (what was requested after it stays in flight) and, loads retiring in order, for the DMA of W step s + 1
+    // requested before it: the next top-of-step barrier publishes both.
+    auto step = [&](int s, i32x4c &ld_raw, float &ld_scale, i32x4c &cm_raw, const float &cm_scale) {
+        c16_barrier();
+        if (kAllGather || a_thread) a_request(ld_raw, ld_scale);
+        b_request(s + PD);
+        const uint32_t fb = oB + (s % NS) * kStageB + fb0;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            i32x4c af[MT], bfr[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) C16_FRAG(af[a], fa0 ^ (kk * 32), a * 2048);
+#pragma unroll
+            for (int b = 0; b < NT; ++b) C16_FRAG(bfr[b], fb ^ (kk * 32), b * 2048);
+            if constexpr (MT == 2 && NT == 6)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]), "+v"(bfr[4]), "+v"(bfr[5]));
+            else if constexpr (MT == 2 && NT == 4)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]));
+            else if constexpr (MT == 2 && NT == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]));
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]), "+v"(bfr[4]), "+v"(bfr[5]), "+v"(bfr[6]), "+v"(bfr[7]));
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, af[a]), __builtin_bit_cast(bf16x8c, bfr[b]), acc[a][b], 0, 0, 0);
+        }
+        c16_barrier();
+        if (kAllGather || a_thread) a_commit(cm_raw, cm_scale, std::integral_constant<int, kInflight>{});
+        else if (PD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");   // a wave without pieces: its DMA of step s + 1
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    if (PD == 2) {
+        for (int s = 0; s < nsteps; s += 2) {
+            step(s, r0_raw, r0_scale, r1_raw, r1_scale);
+            if (s + 1 < nsteps) step(s + 1, r1_raw, r1_scale, r0_raw, r0_scale);
+        }
+    } else {
+        for (int s = 0; s < nsteps; ++s) step(s, r0_raw, r0_scale, r0_raw, r0_scale);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0_raw), "+v"(r1_raw) : : "memory");   // the requests past the last step
+    // ---- epilogue.  C/D layout: MFMA column li of tile b = output column wn + li NT + b, row = wm + 32 a + (reg & 3) + 8 (reg >> 2) + 4 h.
+    // y = bf16(acc + bias): F.linear on bf16 operands returns a bf16 tensor (train_gpt.py:185-186); norm() upcasts it (172-173, 443).
+    // The tile leaves through LDS in halves of 32 MT rows (they fit in the stages of W): a lane packs its NT consecutive outputs of a
+    // row; then 32 lanes take a row, sum its squares, scale and store whole 16-byte pieces.
+    float bv[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) bv[b] = P.bias ? (float)P.bias[wn + li * NT + b] : 0.f;
+    __syncthreads();   // every wave is done with the last step's tiles
+    __bf16 *stage = (__bf16 *)lds_c;   // [WMR][BN]
+    static_assert(WMR * BN * 2 <= NS * kStageB, "a half tile fits in the stages");
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if ((wave >> 2) == half) {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lr = 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;   // row inside the half
+                    uint32_t *dst = (uint32_t *)(stage + lr * BN + wn + li * NT);
+#pragma unroll
+                    for (int b = 0; b < NT; b += 2) {
+                        typedef __bf16 bf16x2c __attribute__((ext_vector_type(2)));
+                        bf16x2c pr;
+                        pr[0] = (__bf16)(acc[a][b][r] + bv[b]);
+                        pr[1] = (__bf16)(acc[a][b + 1][r] + bv[b + 1]);
+                        dst[b / 2] = __builtin_bit_cast(uint32_t, pr);
+                    }
+                }
+        }
+        __syncthreads();
+        constexpr int PP = NT / 2;   // 16-byte pieces of a row per lane: BN / 8 pieces over 32 lanes
+        for (int lr = wave * 2 + h; lr < WMR; lr += 16) {
+            const int row = half * WMR + lr;
+            bf16x8c v[PP];
+            float ss = 0.f;
+#pragma unroll
+            for (int p = 0; p < PP; ++p) {
+                v[p] = *(const bf16x8c *)(stage + lr * BN + 8 * (li + 32 * p));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss += (float)v[p][e] * (float)v[p][e];
+            }
+            float rs = 1.f;
+            if (P.norm_out) {
+#pragma unroll
+                for (int o = 1; o < 32; o <<= 1) ss += __shfl_xor(ss, o, 64);
+                rs = rms_scale(ss, P.Dm, P.eps);
+                if (P.row_rnorm && li == 0 && row < nrows) P.row_rnorm[j0 + row] = rs;
+#pragma unroll
+                for (int p = 0; p < PP; ++p)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[p][e] = (__bf16)((float)v[p][e] * rs);
+            }
+            if (row < nrows) {
+#pragma unroll
+                for (int p = 0; p < PP; ++p)
+                    __builtin_nontemporal_store(v[p], (bf16x8c *)(P.out + (j0 + row) * (int64_t)P.Dm + 8 * (li + 32 * p)));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static size_t c16_lds_base(int MT, int NT, int NS, int bpt);
+template <int MT, int NT, int NS>
+static int launch_c16(const C16Args &P0, hipStream_t stream) {
+    constexpr int BM = 64 * MT;
+    const C16Args &P = P0;
+    const size_t lds = c16_lds_base(MT, NT, NS, P.bpt) + (size_t)P.byte_rows * 4;
+    if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "concat16: needs %zu B of LDS", lds);
+    static std::atomic<uint64_t> ok{0};
+    if (int rc = ensure_max_dyn_lds((const void *)concat16_gemm_kernel<MT, NT, NS>, ok, "concat16_gemm_kernel")) return rc;
+    const int64_t blocks = (P.n + BM - 1) / BM;
+    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "concat16: too many rows");
+    hipLaunchKernelGGL((concat16_gemm_kernel<MT, NT, NS>), dim3((unsigned)blocks), dim3(kC16Threads), lds, stream, P);
+    return check_launch("concat16_gemm_kernel");
+}
+
+static size_t c16_lds_base(int MT, int NT, int NS, int bpt) {
+    return (size_t)NS * 128 * NT * 64 + (size_t)64 * MT * 64 + (((size_t)64 * MT * bpt * 2 + 15) & ~(size_t)15);
+}
+struct C16Shape { int MT, NT, NS; };
+static C16Shape c16_shape(int Dm) {
+    switch (Dm) {
+        case 256: return {2, 2, 3};
+        case 512: return {2, 4, 3};
+        case 768: return {2, 6, 3};
+        default: return {1, 8, 2};   // 1024: two stages of 64 KiB
+    }
+}
+
+// the shapes this kernel takes: bf16, one id tensor, pieces of 8 elements that never straddle a part (Dt, Db multiples of 8),
+// whole 32-deep steps, model_dim = 128 NT with an accumulator tile that fits (NT <= 6 at 128-token tiles, 8 at 64-token tiles),
+// 16-bit byte ids, and the tile's ids and the byte rows' rms factors beside the stages in LDS
+bool concat16_usable(const MotEmbedMixDesc &d) {
+    if (d.dtype != MOT_BF16 || d.ids_b || d.scale_tok || d.scale_byte || d.bpt < 1) return false;
+    const int K = d.tok_dim + d.bpt * d.byte_dim;
+    if ((d.tok_dim & 7) || (d.byte_dim & 7) || (K & 31) || d.byte_rows > 65536) return false;
+    const int Dm = d.model_dim;
+    if (Dm != 256 && Dm != 512 && Dm != 768 && Dm != 1024) return false;
+    if (((uintptr_t)d.weight | (uintptr_t)d.tok_table | (uintptr_t)d.byte_table | (uintptr_t)d.out) & 15) return false;
+    const C16Shape sh = c16_shape(Dm);
+    return c16_lds_base(sh.MT, sh.NT, sh.NS, d.bpt) + (size_t)d.byte_rows * 4 <= 160 * 1024;
+}
+
+// rn_byte: per-row rms factors of the byte table (launch_rows_rnorm), or null when the byte part is not normalised
+int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64_t *ids, int64_t n, const float *rn_byte,
+                    void *out, float *row_rnorm, hipStream_t stream) {
+    C16Args P;
+    P.tokens = tokens; P.ids = ids; P.n = n;
+    P.tok_table = (const __bf16 *)d.tok_table; P.tok_rows = d.tok_rows; P.Dt = d.tok_dim;
+    P.byte_table = (const __bf16 *)d.byte_table; P.byte_rows = d.byte_rows; P.Db = d.byte_dim; P.bpt = d.bpt;
+    P.norm_tok = d.norm_tok; P.byte_rnorm = rn_byte;
+    P.W = (const __bf16 *)d.weight; P.bias = (const __bf16 *)d.bias;
+    P.K = d.tok_dim + d.bpt * d.byte_dim; P.Dm = d.model_dim;
+    P.tok_lo = d.bytes_first ? d.bpt * d.byte_dim : 0; P.byte_lo = d.bytes_first ? 0 : d.tok_dim;
+    P.norm_out = d.norm_out; P.eps = d.eps > 0.f ? d.eps : kBf16Eps;
+    P.out = (__bf16 *)out; P.row_rnorm = d.norm_out ? row_rnorm : nullptr; P.status = d.status;
+    switch (d.model_dim) {
+        case 256: return launch_c16<2, 2, 3>(P, stream);
+        case 512: return launch_c16<2, 4, 3>(P, stream);
+        case 768: return launch_c16<2, 6, 3>(P, stream);
+        default: return launch_c16<1, 8, 2>(P, stream);
+    }
+}
+
+}  // namespace mot

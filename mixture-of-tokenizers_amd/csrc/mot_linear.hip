@@ -498,6 +498,12 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
     // table built once per call); otherwise from the two seam gathers
     const int vec = bf ? 8 : 4;
     const bool one_kernel = !d.ids_b && (Dt % vec) == 0 && (Db % vec) == 0;
+    // bf16 at the shapes mot_concat16.hip takes: gather, contraction, bias and output norm are ONE kernel and u is never built
+    const bool fused16 = bf && !(d.flags & MOT_FLAG_LINEAR_COMPOSED) && concat16_usable(d);
+    if (fused16) {
+        if (d.norm_byte && (rc = launch_rows_rnorm(d.byte_table, d.byte_rows, Db, eps, rn, d.dtype, stream))) return rc;
+        return launch_concat16(d, d.tokens, d.ids_a, N, d.norm_byte ? rn : nullptr, d.out, d.out_row_rnorm, stream);
+    }
     if (one_kernel && d.norm_byte && (rc = launch_rows_rnorm(d.byte_table, d.byte_rows, Db, eps, rn, d.dtype, stream))) return rc;
     for (int64_t r0 = 0; r0 < N; r0 += kSlabRows) {
         const int64_t n = N - r0 < kSlabRows ? N - r0 : kSlabRows;

@@ -19,12 +19,14 @@ from . import _capi as capi
 # in MotEmbedMixDesc.flags).  Every call can override them with one_launch= / mean_generic= / du_fp32=.
 _ENV_FLAGS = ((capi.FLAG_LINEAR_ONE_LAUNCH if os.environ.get("MOT_LIN_FUSED") else 0)
               | (capi.FLAG_MEAN_GENERIC if os.environ.get("MOT_NO_MEAN_LDS") else 0)
-              | (capi.FLAG_BWD_DU_FP32 if os.environ.get("MOT_NO_DU16") else 0))
+              | (capi.FLAG_BWD_DU_FP32 if os.environ.get("MOT_NO_DU16") else 0)
+              | (capi.FLAG_LINEAR_COMPOSED if os.environ.get("MOT_LIN_COMPOSED") else 0))
 
 
-def _flags(one_launch=None, mean_generic=None, du_fp32=None) -> int:
+def _flags(one_launch=None, mean_generic=None, du_fp32=None, composed=None) -> int:
     f = _ENV_FLAGS
-    for bit, v in ((capi.FLAG_LINEAR_ONE_LAUNCH, one_launch), (capi.FLAG_MEAN_GENERIC, mean_generic), (capi.FLAG_BWD_DU_FP32, du_fp32)):
+    for bit, v in ((capi.FLAG_LINEAR_ONE_LAUNCH, one_launch), (capi.FLAG_MEAN_GENERIC, mean_generic), (capi.FLAG_BWD_DU_FP32, du_fp32),
+                   (capi.FLAG_LINEAR_COMPOSED, composed)):
         if v is not None:
             f = (f | bit) if v else (f & ~bit)
     return f
@@ -191,13 +193,14 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
               scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
               out: torch.Tensor | None = None, return_ids: bool = False,
               counters: torch.Tensor | None = None, row_rnorm: torch.Tensor | None = None,
-              one_launch: bool | None = None, mean_generic: bool | None = None,
+              one_launch: bool | None = None, mean_generic: bool | None = None, composed: bool | None = None,
               _plan: bool = False) -> torch.Tensor | MixResult:
     """One fused launch of mot_embed_mix_fwd; see include/mot.h for the per-token formula.
 
     tokens (B, T) integer.  Byte ids either come from `ttb` (+ `pull` = "left" | "right" | None,
     + `add_padded`) inside the kernel, or are given as `ids_a` / `ids_b` (B, T*bpt) int64.
     `scale_*` are 0-dim/1-element DEVICE tensors (learned scalars are read on the device).
+    `composed` (bf16 concat_linear: the separate gather / GEMM / norm kernels instead of the one gather-GEMM),
     `one_launch` (concat_linear: the one-launch tile kernel instead of the composed kernels) and `mean_generic` (mean: the
     whole-row kernel instead of the LDS column-slice kernel) override the import-time defaults (MotEmbedMixDesc.flags).
     """
@@ -218,7 +221,7 @@ def _embed_mix_fwd(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: to
     d = capi.MotEmbedMixDesc()
     d.struct_size = C.sizeof(capi.MotEmbedMixDesc)
     d.dtype = capi.dtype_code(fdt)
-    d.flags = _flags(one_launch, mean_generic)
+    d.flags = _flags(one_launch, mean_generic, composed=composed)
     d.n_rows, d.tokens_per_row, d.bpt, d.mode = B, T, int(bpt), m
     d.tokens = capi.ptr(tok)
     d.tok_table, d.tok_rows, d.tok_dim = capi.ptr(tt), tt.shape[0], tt.shape[1]
