@@ -19,6 +19,8 @@
 // One barrier per step; the DMA of step s + 1 and the gathered pieces of step s + 1 are in flight while step s multiplies.
 #include "mot_mix.hpp"
 #include <type_traits>
+// (clang wants the explicit captures below for operands of inline asm inside generic lambdas, and then calls them unused)
+#pragma clang diagnostic ignored "-Wunused-lambda-capture"
 
 namespace mot {
 
@@ -44,6 +46,12 @@ struct C16Args {
 };
 
 constexpr int kC16Threads = 512;
+#ifdef C16_STAMPS   // dev: wall-clock stamps (10 ns units) of workgroup phases, printed once by the launcher
+__device__ unsigned long long c16_stamps[4096 * 8];
+#define C16_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) c16_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define C16_STAMP(i) do {} while (0)
+#endif
 typedef int i32x4c __attribute__((ext_vector_type(4)));
 
 // LDS reads the COMPILER must not see.  hipcc orders every LDS read it emits behind every LDS-DMA still in flight (it cannot
@@ -61,6 +69,13 @@ __device__ __forceinline__ float lds_f32_now(uint32_t addr) {
     float v;
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
     return v;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
 }
 // workgroup barrier that waits for this wave's LDS traffic only (no vmcnt drain: the DMA and the gathered pieces stay in flight)
 __device__ __forceinline__ void c16_barrier() {
@@ -96,6 +111,10 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
         const int nrow = strip * WNR + (within & 31) * NT + (within >> 5);
         goff[i] = (uint32_t)(nrow * K + 8 * (((lane & 3) ^ (q >> 2)) & 3)) * 2u;
     }
+#ifndef C16_X
+#define C16_X 0
+#endif
+    C16_STAMP(0);
     const int nsteps = K / 32;
     auto b_request = [&](int s) {   // (a step past the end re-reads the last one into a stage nobody reads: the loop stays branch-free)
         char *sB = lds_c + (s % NS) * kStageB;
@@ -163,7 +182,9 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
         slot = first / P.Db; within = first - slot * P.Db;
     }
     const int dslot = 32 / P.Db, dwithin = 32 - dslot * P.Db;
+    C16_STAMP(1);
     __syncthreads();   // sIds, sRn  (hipcc drains the DMA of the first stages here: once per tile)
+    C16_STAMP(2);
     auto a_request = [&](i32x4c &raw, float &scale) {
         const int kt = ak - P.tok_lo;
         const bool in_tok = (unsigned)kt < (unsigned)P.Dt;
@@ -181,10 +202,8 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
         slot = in_tok ? slot : s2;
         ak += 32;
     };
-    // scale in fp32, round once to bf16 (the reference's norm() output), into the step's tile.  INFLIGHT = vector-memory operations
-    // requested after this piece AND after the DMA of the same step that may stay in flight (loads retire in order)
-    auto a_commit = [&](i32x4c &raw_bits, float scale, auto inflight) {
-        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(raw_bits) : "n"(decltype(inflight)::value) : "memory");
+    // scale in fp32, round once to bf16 (the reference's norm() output), into the step's tile (the caller has waited for the piece)
+    auto a_commit = [&](const i32x4c &raw_bits, float scale) {
         const bf16x8c raw = __builtin_bit_cast(bf16x8c, raw_bits);
         bf16x8c v;
 #pragma unroll
@@ -208,43 +227,72 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     if (kAllGather || a_thread) {
         a_request(r0_raw, r0_scale);
         if (PD == 2) a_request(r1_raw, r1_scale);
-        a_commit(r0_raw, r0_scale, std::integral_constant<int, PD - 1>{});
+        asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0_raw) : "n"(PD - 1) : "memory");
+        a_commit(r0_raw, r0_scale);
     }
-    // step s: [barrier: stage s of W and the gathered tile s are in LDS for everyone] request W step s + PD (DMA) and piece s + PD
-    // (registers), multiply step s, [barrier: everyone has read the gathered tile], commit piece s + 1 -- which waits for that piece
-    // with a COUNTED vmcnt (what was requested after it stays in flight) and, loads retiring in order, for the DMA of W step s + 1
-    // requested before it: the next top-of-step barrier publishes both.
+    // ---- the step.  One wave's share of step s is NP = 2 NT "positions" (kk, b) of MT MFMAs each; all eight waves run in lockstep
+    // between the two barriers of a step, so whatever is not an MFMA has to be issued BETWEEN MFMAs or the matrix pipes idle:
+    //   * the fragments of W roll through four register slots, read three positions ahead (LDS latency under the MFMAs of the
+    //     positions in between), the first three of a step right behind the previous step's second barrier;
+    //   * the NT DMA instructions of W step s + PD go out one per position, the gathered piece s + PD at position NP - 3 (its
+    //     LDS id read drains the LDS queue: every fragment of the step is requested by then);
+    //   * waits are COUNTED: lgkmcnt(n) leaves the younger fragment reads in flight, vmcnt(NT + 1) the requests of this step.
+    // Order: [barrier 1: the gathered tile s is committed] fragments of the gathered tile; positions; wait for piece s + 1 and the
+    // DMA of W step s + 1 (loads retire in order: one count covers both); [barrier 2: everyone has read tile s, W step s + 1 is
+    // in LDS for everyone] first fragments of W step s + 1; commit piece s + 1.
+    constexpr int NP = 2 * NT;
+    i32x4c af[2 * MT], bq[4];
+    auto frag_b = [&bq](auto idx, uint32_t fb) {   // fragment idx = (kk, b) of the stage at fb -> slot idx % 4
+        constexpr int i = decltype(idx)::value;
+        C16_FRAG(bq[i % 4], fb ^ ((i / NT) * 32), (i % NT) * 2048);
+    };
+    auto dma_piece = [&](int s, auto ic) {
+        constexpr int i = decltype(ic)::value;
+        char *sB = lds_c + (s % NS) * kStageB;
+        const char *g = (const char *)P.W + (goff[i] + 64u * (uint32_t)min(s, nsteps - 1));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                         (__attribute__((address_space(3))) void *)(sB + (i * 8 + wave) * 1024), 16, 0, 0);
+    };
     auto step = [&](int s, i32x4c &ld_raw, float &ld_scale, i32x4c &cm_raw, const float &cm_scale) {
         c16_barrier();
-        if (kAllGather || a_thread) a_request(ld_raw, ld_scale);
-        b_request(s + PD);
         const uint32_t fb = oB + (s % NS) * kStageB + fb0;
+        static_for<0, 2 * MT>([&af, fa0](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            C16_FRAG(af[j], fa0 ^ ((j / MT) * 32), (j % MT) * 2048);
+        });
+        static_for<0, NP>([&, &af = af, &bq = bq](auto pc) {
+            constexpr int p = decltype(pc)::value, kk = p / NT, b = p % NT;
+            if constexpr (p == (NP >= 3 ? NP - 3 : 0))
+                if (kAllGather || a_thread) a_request(ld_raw, ld_scale);
+            // LDS reads behind barrier 1, in order: the 2 MT fragments of the gathered tile, then W fragments 3, 4, ... (one per position)
+            constexpr int issued = 2 * MT + (p < NP - 3 ? p : NP - 3);
+            constexpr int need_b = p >= 3 ? 2 * MT + p - 3 : -1;
+            constexpr int need_a = p == 0 ? MT - 1 : (p == NT ? 2 * MT - 1 : -1);
+            constexpr int need = need_b > need_a ? need_b : need_a;
+            if constexpr (need >= 0) {
+                if constexpr (MT == 2) asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(bq[p % 4]), "+v"(af[kk * MT]), "+v"(af[kk * MT + 1]) : "n"(issued - need - 1));
+                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(bq[p % 4]), "+v"(af[kk * MT]) : "n"(issued - need - 1));
+            } else {
+                asm volatile("" : "+v"(bq[p % 4]));
+            }
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            i32x4c af[MT], bfr[NT];
-#pragma unroll
-            for (int a = 0; a < MT; ++a) C16_FRAG(af[a], fa0 ^ (kk * 32), a * 2048);
-#pragma unroll
-            for (int b = 0; b < NT; ++b) C16_FRAG(bfr[b], fb ^ (kk * 32), b * 2048);
-            if constexpr (MT == 2 && NT == 6)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]), "+v"(bfr[4]), "+v"(bfr[5]));
-            else if constexpr (MT == 2 && NT == 4)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]));
-            else if constexpr (MT == 2 && NT == 2)
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(af[1]), "+v"(bfr[0]), "+v"(bfr[1]));
-            else
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]), "+v"(bfr[0]), "+v"(bfr[1]), "+v"(bfr[2]), "+v"(bfr[3]), "+v"(bfr[4]), "+v"(bfr[5]), "+v"(bfr[6]), "+v"(bfr[7]));
-#pragma unroll
-            for (int b = 0; b < NT; ++b)
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, af[a]), __builtin_bit_cast(bf16x8c, bfr[b]), acc[a][b], 0, 0, 0);
-        }
-        c16_barrier();
-        if (kAllGather || a_thread) a_commit(cm_raw, cm_scale, std::integral_constant<int, kInflight>{});
+            for (int a = 0; a < MT; ++a)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8c, af[kk * MT + a]), __builtin_bit_cast(bf16x8c, bq[p % 4]),
+                                                                    acc[a][b], 0, 0, 0);
+            if constexpr (p + 3 < NP) frag_b(std::integral_constant<int, p + 3>{}, fb);
+            if constexpr (p < kDma) dma_piece(s + PD, pc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (kAllGather || a_thread) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cm_raw) : "n"(kInflight) : "memory");
         else if (PD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");   // a wave without pieces: its DMA of step s + 1
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        c16_barrier();
+        const uint32_t fbn = oB + ((s + 1) % NS) * kStageB + fb0;
+        static_for<0, 3>([&](auto ic) { frag_b(ic, fbn); });
+        if (kAllGather || a_thread) a_commit(cm_raw, cm_scale);
     };
+    static_for<0, 3>([&](auto ic) { frag_b(ic, oB + fb0); });   // (the stage landed in front of the barrier above)
+    C16_STAMP(3);
     if (PD == 2) {
         for (int s = 0; s < nsteps; s += 2) {
             step(s, r0_raw, r0_scale, r1_raw, r1_scale);
@@ -253,15 +301,27 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     } else {
         for (int s = 0; s < nsteps; ++s) step(s, r0_raw, r0_scale, r0_raw, r0_scale);
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(r0_raw), "+v"(r1_raw) : : "memory");   // the requests past the last step
+    // What was requested past the last step is still on its way INTO registers the compiler considers free from here on: the
+    // fragment reads behind the last barrier, the gathered pieces.  Hold the registers until everything has landed.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(r0_raw), "+v"(r1_raw), "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]) : : "memory");
+    C16_STAMP(4);
     // ---- epilogue.  C/D layout: MFMA column li of tile b = output column wn + li NT + b, row = wm + 32 a + (reg & 3) + 8 (reg >> 2) + 4 h.
     // y = bf16(acc + bias): F.linear on bf16 operands returns a bf16 tensor (train_gpt.py:185-186); norm() upcasts it (172-173, 443).
     // The tile leaves through LDS in halves of 32 MT rows (they fit in the stages of W): a lane packs its NT consecutive outputs of a
     // row; then 32 lanes take a row, sum its squares, scale and store whole 16-byte pieces.
+    if (C16_X & 32) {
+        if (P.n < 0)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) P.out[tid] = (__bf16)acc[a][b][0];
+        return;
+    }
     float bv[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b) bv[b] = P.bias ? (float)P.bias[wn + li * NT + b] : 0.f;
     __syncthreads();   // every wave is done with the last step's tiles
+    C16_STAMP(5);
     __bf16 *stage = (__bf16 *)lds_c;   // [WMR][BN]
     static_assert(WMR * BN * 2 <= NS * kStageB, "a half tile fits in the stages");
 #pragma unroll
@@ -306,13 +366,14 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[p][e] = (__bf16)((float)v[p][e] * rs);
             }
-            if (row < nrows) {
+            if (row < nrows && !(C16_X & 8)) {
 #pragma unroll
                 for (int p = 0; p < PP; ++p)
                     __builtin_nontemporal_store(v[p], (bf16x8c *)(P.out + (j0 + row) * (int64_t)P.Dm + 8 * (li + 32 * p)));
             }
         }
         __syncthreads();
+        C16_STAMP(6 + half);
     }
 }
 
@@ -328,6 +389,27 @@ static int launch_c16(const C16Args &P0, hipStream_t stream) {
     const int64_t blocks = (P.n + BM - 1) / BM;
     if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "concat16: too many rows");
     hipLaunchKernelGGL((concat16_gemm_kernel<MT, NT, NS>), dim3((unsigned)blocks), dim3(kC16Threads), lds, stream, P);
+#ifdef C16_STAMPS
+    static int calls = 0;
+    if (++calls == 60) {
+        static unsigned long long h[4096 * 8];
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(c16_stamps), sizeof(h));
+        const int nb = (int)(blocks < 4096 ? blocks : 4096);
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < nb; ++b) t0 = h[b * 8] < t0 ? h[b * 8] : t0;
+        double sum[8] = {0}, mx[8] = {0};
+        for (int b = 0; b < nb; ++b)
+            for (int i = 0; i < 8; ++i) { const double v = (double)(h[b * 8 + i] - t0) * 0.01; sum[i] += v; mx[i] = v > mx[i] ? v : mx[i]; }
+        fprintf(stderr, "c16 stamps (us since first start; mean / max over %d workgroups):", nb);
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "  [%d] %.1f/%.1f", i, sum[i] / nb, mx[i]);
+        fprintf(stderr, "\n  first-round groups only (start < 2 us):");
+        double s2[8] = {0}; int n2 = 0;
+        for (int b = 0; b < nb; ++b) if ((h[b * 8] - t0) < 200) { ++n2; for (int i = 0; i < 8; ++i) s2[i] += (double)(h[b * 8 + i] - t0) * 0.01; }
+        for (int i = 0; i < 8; ++i) fprintf(stderr, "  [%d] %.1f", i, s2[i] / (n2 ? n2 : 1));
+        fprintf(stderr, "  (%d groups)\n", n2);
+    }
+#endif
     return check_launch("concat16_gemm_kernel");
 }
 
