@@ -481,6 +481,8 @@ def main(argv=None):
                                "frac": tf / peak, "traffic": traffic,
                                "kernel": (("embed_mix_linear_kernel" if args.dtype == "f32" else "embed_mix_linear_bf16_kernel")
                                           if os.environ.get("MOT_LIN_FUSED") else
+                                          ("wave_ids16_kernel + " if args.ids == "fused" else "") + "concat16_gemm_kernel (whole call)"
+                                          if args.dtype == "bf16" and not os.environ.get("MOT_LIN_COMPOSED") else
                                           ("tokens_to_bytes + pull_bytes + " if args.ids == "fused" else "") + "concat_rows + " +
                                           ("gemm_rows_bt_kernel" if args.dtype == "f32" else "gemm_rows_bf16_kernel") +
                                           " + rows_rms_inplace (whole call)"),

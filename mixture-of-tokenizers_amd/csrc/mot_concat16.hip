@@ -17,7 +17,7 @@
 //   * the output tile leaves through LDS as whole 16-byte pieces (the composed kernel's 2-byte lane stores were a measurable part
 //     of its epilogue).
 // One barrier per step; the DMA of step s + 1 and the gathered pieces of step s + 1 are in flight while step s multiplies.
-#include "mot_mix.hpp"
+#include "mot_wave.hpp"
 #include <type_traits>
 // (clang wants the explicit captures below for operands of inline asm inside generic lambdas, and then calls them unused)
 #pragma clang diagnostic ignored "-Wunused-lambda-capture"
@@ -29,12 +29,14 @@ typedef float f32x16c __attribute__((ext_vector_type(16)));
 
 struct C16Args {
     const int32_t *tokens;     // [n]
-    const int64_t *ids;        // [n, bpt]
+    const int64_t *ids;        // [n, bpt] as the reference's loader emits them, or
+    const uint16_t *ids16;     // [n, bpt] compact and range-checked, from wave_ids16_kernel (ids pulled from the token->byte table)
     int64_t n;
     const __bf16 *tok_table; int64_t tok_rows; int Dt;
     const __bf16 *byte_table; int64_t byte_rows; int Db; int bpt;
     int norm_tok;              // token rows are rms-normalised (factor computed per tile, below)
-    const float *byte_rnorm;   // [byte_rows] rms factors of the byte table, or null (no byte norm)
+    const float *byte_rnorm;   // [byte_rows] rms factors of the byte table, or null: no byte norm, or
+    int norm_byte_here;        // the workgroups compute the factors themselves (tables of up to kC16NormHere rows)
     const __bf16 *W;           // [Dm, K]
     const __bf16 *bias;        // [Dm] or null
     int K, Dm, tok_lo, byte_lo;
@@ -46,6 +48,7 @@ struct C16Args {
 };
 
 constexpr int kC16Threads = 512;
+constexpr int kC16NormHere = 1024;
 #ifdef C16_STAMPS   // dev: wall-clock stamps (10 ns units) of workgroup phases, printed once by the launcher
 __device__ unsigned long long c16_stamps[4096 * 8];
 #define C16_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 4096) c16_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
@@ -111,9 +114,6 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
         const int nrow = strip * WNR + (within & 31) * NT + (within >> 5);
         goff[i] = (uint32_t)(nrow * K + 8 * (((lane & 3) ^ (q >> 2)) & 3)) * 2u;
     }
-#ifndef C16_X
-#define C16_X 0
-#endif
     C16_STAMP(0);
     const int nsteps = K / 32;
     auto b_request = [&](int s) {   // (a step past the end re-reads the last one into a stage nobody reads: the loop stays branch-free)
@@ -128,31 +128,72 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     };
     b_request(0);
     if (PD == 2) b_request(1);
-    // ---- ids of the tile's tokens -> LDS (clamped; rows past the batch repeat the last valid token: computed, never stored)
-    for (int i0 = tid; i0 < BM * bpt; i0 += 4 * kC16Threads) {   // four loads in flight per thread
-        int64_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + u * kC16Threads, BM * bpt - 1);
-            v[u] = P.ids[(j0 + min(i / bpt, nrows - 1)) * bpt + i % bpt];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * kC16Threads;
-            if ((uint64_t)v[u] >= (uint64_t)P.byte_rows) { if (P.status) atomicOr(P.status, kStatusByteOor); v[u] = 0; }
-            if (i < BM * bpt) sIds[i] = (uint16_t)v[u];
-        }
-    }
-    for (int i = tid; i < (int)P.byte_rows; i += kC16Threads) sRn[i] = P.byte_rnorm ? P.byte_rnorm[i] : 1.f;
-    // ---- this thread's piece of the gathered operand: row arow, logical 16-byte piece apiece of every 64-byte step row
+    // ---- the tile's own inputs.  Everything that does not depend on another load is requested first (the token id, the byte ids,
+    // the byte rows' rms factors), so that the prologue costs two memory round trips -- ids, then the token rows for their norm --
+    // instead of one per item.
     const bool a_thread = tid < BM * 4;   // (whole waves: BM * 4 is a multiple of 64)
     const int arow = tid >> 2, apiece = tid & 3;
-    int tok = 0;
-    float rn_tok = 1.f;
-    if (a_thread) {
-        tok = P.tokens[j0 + min(arow, nrows - 1)];
-        if ((uint64_t)(uint32_t)tok >= (uint64_t)P.tok_rows) { if (P.status) atomicOr(P.status, kStatusTokenOor); tok = 0; }
+    int tok = a_thread ? P.tokens[j0 + min(arow, nrows - 1)] : 0;
+    const int n_ids = nrows * bpt;        // (rows past the batch repeat the last valid token: computed, never stored)
+    if (P.ids16) {   // compact ids from the wave-local index pass: 8 bytes per thread and trip
+        for (int i0 = tid * 4; i0 < BM * bpt; i0 += 4 * kC16Threads) {
+            uint16_t v[4];
+            if (i0 + 3 < n_ids && (bpt & 3) == 0) {
+                const uint2 w = *(const uint2 *)(P.ids16 + j0 * bpt + i0);
+                v[0] = (uint16_t)w.x; v[1] = (uint16_t)(w.x >> 16); v[2] = (uint16_t)w.y; v[3] = (uint16_t)(w.y >> 16);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u, r = min(i / bpt, nrows - 1);
+                    v[u] = P.ids16[(j0 + r) * bpt + i % bpt];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u < BM * bpt) sIds[i0 + u] = v[u];
+        }
+    } else {
+        for (int i0 = tid; i0 < BM * bpt; i0 += 4 * kC16Threads) {   // four loads in flight per thread
+            int64_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u * kC16Threads, BM * bpt - 1);
+                v[u] = P.ids[(j0 + min(i / bpt, nrows - 1)) * bpt + i % bpt];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kC16Threads;
+                if ((uint64_t)v[u] >= (uint64_t)P.byte_rows) { if (P.status) atomicOr(P.status, kStatusByteOor); v[u] = 0; }
+                if (i < BM * bpt) sIds[i] = (uint16_t)v[u];
+            }
+        }
     }
+    // rms factors of the byte rows: from the caller's table, or (small tables: norm_byte_here) computed here, a thread per row --
+    // the table is L2-resident and a separate launch for 458 rows costs more than the 29 KB every workgroup re-reads
+    for (int i = tid; i < (int)P.byte_rows; i += kC16Threads) {
+        float r = 1.f;
+        if (P.byte_rnorm) r = P.byte_rnorm[i];
+        else if (P.norm_byte_here) {
+            float ss = 0.f;
+            const __bf16 *brow = P.byte_table + (int64_t)i * P.Db;
+            for (int p0 = 0; p0 < P.Db / 8; p0 += 4) {   // four loads in flight
+                bf16x8c v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const bf16x8c *)(brow + 8 * min(p0 + u, P.Db / 8 - 1));
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (p0 + u < P.Db / 8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ss += (float)v[u][e] * (float)v[u][e];
+                    }
+            }
+            r = rms_scale(ss, P.Db, P.eps);
+        }
+        sRn[i] = r;
+    }
+    // ---- this thread's piece of the gathered operand: row arow, logical 16-byte piece apiece of every 64-byte step row
+    float rn_tok = 1.f;
+    if ((uint64_t)(uint32_t)tok >= (uint64_t)P.tok_rows) { if (P.status) atomicOr(P.status, kStatusTokenOor); tok = 0; }
     const __bf16 *trow = P.tok_table + (int64_t)tok * P.Dt;
     if (P.norm_tok) {   // the four threads of a row share its sum of squares (the row comes back out of L2 in the steps below)
         float ss = 0.f;
@@ -281,7 +322,6 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
                                                                     acc[a][b], 0, 0, 0);
             if constexpr (p + 3 < NP) frag_b(std::integral_constant<int, p + 3>{}, fb);
             if constexpr (p < kDma) dma_piece(s + PD, pc);
-            __builtin_amdgcn_sched_barrier(0);
         });
         if (kAllGather || a_thread) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(cm_raw) : "n"(kInflight) : "memory");
         else if (PD == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kDma) : "memory");   // a wave without pieces: its DMA of step s + 1
@@ -309,14 +349,6 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     // y = bf16(acc + bias): F.linear on bf16 operands returns a bf16 tensor (train_gpt.py:185-186); norm() upcasts it (172-173, 443).
     // The tile leaves through LDS in halves of 32 MT rows (they fit in the stages of W): a lane packs its NT consecutive outputs of a
     // row; then 32 lanes take a row, sum its squares, scale and store whole 16-byte pieces.
-    if (C16_X & 32) {
-        if (P.n < 0)
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) P.out[tid] = (__bf16)acc[a][b][0];
-        return;
-    }
     float bv[NT];
 #pragma unroll
     for (int b = 0; b < NT; ++b) bv[b] = P.bias ? (float)P.bias[wn + li * NT + b] : 0.f;
@@ -366,7 +398,7 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[p][e] = (__bf16)((float)v[p][e] * rs);
             }
-            if (row < nrows && !(C16_X & 8)) {
+            if (row < nrows) {
 #pragma unroll
                 for (int p = 0; p < PP; ++p)
                     __builtin_nontemporal_store(v[p], (bf16x8c *)(P.out + (j0 + row) * (int64_t)P.Dm + 8 * (li + 32 * p)));
@@ -413,6 +445,63 @@ static int launch_c16(const C16Args &P0, hipStream_t stream) {
     return check_launch("concat16_gemm_kernel");
 }
 
+// ------------------------------------------------------------------------------------------ ids pulled from the token->byte table
+// The byte-index work of the loader (tokens_to_bytes + pull, data_creation.py:60-76, 79-176, 179-305) for the gather-GEMM above:
+// the wave-local indexer of the fused SUM kernel (mot_wave.hpp: a unit of 16 tokens per wave, its 64-token window, halo walk
+// across the window's edge) writes the pulled ids ONCE, as 16-bit values (2 bytes per slot instead of the two int64 tensors the
+// separate index kernels write and read back: 2 MB instead of 2 x 8 + 8 MB at 65 536 tokens), range-checked, plus the int64 parity
+// outputs and the pad statistics when the caller asked for them.
+constexpr int kIds16Unit = 16;
+template <int DIR, typename E>
+__global__ __launch_bounds__(kThreads) void wave_ids16_kernel(const MixArgs A, uint16_t *__restrict__ ids16) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_wave[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t unit_id = (int64_t)blockIdx.x * kWaves + wave;
+    if (unit_id >= A.n_units) return;             // no workgroup barrier below: a wave may leave on its own
+    const int64_t row = unit_id / A.units_per_row;
+    const int64_t u0 = (unit_id - row * A.units_per_row) * A.unit;
+    const int ntok = (int)min((int64_t)A.unit, A.T - u0);
+    const WaveLds W = wave_lds_carve(lds_wave + (size_t)wave * A.wave_lds, A.unit, A.bpt, false, DIR != kPullNone ? (int)sizeof(E) : 0);
+    WaveIndexer<DIR, E> ix(A, W, row, u0, ntok, false);
+    ix.tokens();
+    ix.load_rows();
+    ix.finish();
+    const int bpt = A.bpt, sv = bpt | 1, n = ntok * bpt;
+    uint16_t *dst = ids16 + (row * A.T + u0) * bpt;
+    const float inv = 1.0f / (float)bpt;
+    for (int i = lane; i < n; i += 64) {
+        const int t = __float2int_rd(((float)i + 0.5f) * inv);     // i / bpt, exact for i < 2^22
+        dst[i] = (uint16_t)W.ids[t * sv + (i - t * bpt)];
+    }
+}
+
+int launch_wave_ids16(const MotEmbedMixDesc &d, uint16_t *ids16, hipStream_t stream) {
+    MixArgs A;
+    fill_mix_args(A, d);
+    A.unit = kIds16Unit;
+    A.units_per_row = (d.tokens_per_row + A.unit - 1) / A.unit;
+    A.n_units = d.n_rows * A.units_per_row;
+    const int64_t blocks = (A.n_units + kWaves - 1) / kWaves;
+    if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "concat16: too many units");
+    if (blocks == 0) return MOT_OK;
+    A.wave_lds = (int)wave_lds_bytes(A.unit, d.bpt, false, d.pull_dir != MOT_PULL_NONE ? d.ttb_elem_bytes : 0);
+    const size_t lds = (size_t)A.wave_lds * kWaves;
+    if (lds > 64 * 1024) return set_error(MOT_EUNSUPPORTED, "concat16: the index pass needs %zu B of LDS", lds);
+#define MOT_IDS16_LAUNCH(DIR, E) hipLaunchKernelGGL((wave_ids16_kernel<DIR, E>), dim3((unsigned)blocks), dim3(kThreads), lds, stream, A, ids16)
+    if (d.ttb_elem_bytes == 2) {
+        if (d.pull_dir == MOT_PULL_LEFT) MOT_IDS16_LAUNCH(kPullLeft, int16_t);
+        else if (d.pull_dir == MOT_PULL_RIGHT) MOT_IDS16_LAUNCH(kPullRight, int16_t);
+        else MOT_IDS16_LAUNCH(kPullNone, int16_t);
+    } else {
+        if (d.pull_dir == MOT_PULL_LEFT) MOT_IDS16_LAUNCH(kPullLeft, int32_t);
+        else if (d.pull_dir == MOT_PULL_RIGHT) MOT_IDS16_LAUNCH(kPullRight, int32_t);
+        else MOT_IDS16_LAUNCH(kPullNone, int32_t);
+    }
+#undef MOT_IDS16_LAUNCH
+    return check_launch("wave_ids16_kernel");
+}
+
 static size_t c16_lds_base(int MT, int NT, int NS, int bpt) {
     return (size_t)NS * 128 * NT * 64 + (size_t)64 * MT * 64 + (((size_t)64 * MT * bpt * 2 + 15) & ~(size_t)15);
 }
@@ -429,6 +518,7 @@ static C16Shape c16_shape(int Dm) {
 // the shapes this kernel takes: bf16, one id tensor, pieces of 8 elements that never straddle a part (Dt, Db multiples of 8),
 // whole 32-deep steps, model_dim = 128 NT with an accumulator tile that fits (NT <= 6 at 128-token tiles, 8 at 64-token tiles),
 // 16-bit byte ids, and the tile's ids and the byte rows' rms factors beside the stages in LDS
+bool concat16_norm_in_kernel(const MotEmbedMixDesc &d) { return d.byte_rows <= kC16NormHere; }
 bool concat16_usable(const MotEmbedMixDesc &d) {
     if (d.dtype != MOT_BF16 || d.ids_b || d.scale_tok || d.scale_byte || d.bpt < 1) return false;
     const int K = d.tok_dim + d.bpt * d.byte_dim;
@@ -440,14 +530,15 @@ bool concat16_usable(const MotEmbedMixDesc &d) {
     return c16_lds_base(sh.MT, sh.NT, sh.NS, d.bpt) + (size_t)d.byte_rows * 4 <= 160 * 1024;
 }
 
-// rn_byte: per-row rms factors of the byte table (launch_rows_rnorm), or null when the byte part is not normalised
-int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64_t *ids, int64_t n, const float *rn_byte,
+// rn_byte: per-row rms factors of the byte table (launch_rows_rnorm); null when the byte part is not normalised or the table is
+// small enough for the workgroups to compute them (concat16_norm_in_kernel)
+int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64_t *ids, const uint16_t *ids16, int64_t n, const float *rn_byte,
                     void *out, float *row_rnorm, hipStream_t stream) {
     C16Args P;
-    P.tokens = tokens; P.ids = ids; P.n = n;
+    P.tokens = tokens; P.ids = ids; P.ids16 = ids16; P.n = n;
     P.tok_table = (const __bf16 *)d.tok_table; P.tok_rows = d.tok_rows; P.Dt = d.tok_dim;
     P.byte_table = (const __bf16 *)d.byte_table; P.byte_rows = d.byte_rows; P.Db = d.byte_dim; P.bpt = d.bpt;
-    P.norm_tok = d.norm_tok; P.byte_rnorm = rn_byte;
+    P.norm_tok = d.norm_tok; P.byte_rnorm = rn_byte; P.norm_byte_here = d.norm_byte && !rn_byte;
     P.W = (const __bf16 *)d.weight; P.bias = (const __bf16 *)d.bias;
     P.K = d.tok_dim + d.bpt * d.byte_dim; P.Dm = d.model_dim;
     P.tok_lo = d.bytes_first ? d.bpt * d.byte_dim : 0; P.byte_lo = d.bytes_first ? 0 : d.tok_dim;

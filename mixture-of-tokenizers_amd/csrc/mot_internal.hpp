@@ -62,8 +62,10 @@ int launch_embed_mix_linear_composed(const MotEmbedMixDesc &d, hipStream_t strea
 // C[n][c] = sum_r A[n][r] * B[c][r] (+ bias[c]) for bf16 A, B (and bias), fp32 accumulation, C bf16 or fp32
 // mot_concat16.hip: gather + contraction + bias + output norm of the bf16 concat + linear mixin in one kernel
 bool concat16_usable(const MotEmbedMixDesc &d);
-int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64_t *ids, int64_t n, const float *rn_byte, void *out, float *row_rnorm,
-                    hipStream_t stream);
+bool concat16_norm_in_kernel(const MotEmbedMixDesc &d);   // the byte rows' rms factors need no table from the caller
+int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64_t *ids, const uint16_t *ids16, int64_t n, const float *rn_byte,
+                    void *out, float *row_rnorm, hipStream_t stream);
+int launch_wave_ids16(const MotEmbedMixDesc &d, uint16_t *ids16, hipStream_t stream);   // ids from the token->byte table, 16-bit, + parity outputs
 int launch_gemm_rows_bf16(const void *A, int lda, int64_t n, const void *B, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
                           const void *bias, hipStream_t stream);
 int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream);

@@ -452,9 +452,20 @@ static int launch_composed_from_ttb(const MotEmbedMixDesc &d, hipStream_t stream
     if (!d.workspace || d.workspace_bytes < need)
         return set_error(MOT_EWORKSPACE, "embed_mix concat_linear: needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
     int64_t *ws_ids = (int64_t *)((float *)d.workspace + composed_floats(d) + composed_rnorm_floats(d));
+    int rc;
+    // bf16 at the shapes of mot_concat16.hip: one wave-local index pass (16-bit ids, parity outputs and statistics included) and
+    // the gather-GEMM
+    if (d.dtype == MOT_BF16 && !(d.flags & MOT_FLAG_LINEAR_COMPOSED) && !d.add_padded && concat16_usable(d)) {
+        if (N == 0) return MOT_OK;
+        uint16_t *ids16 = (uint16_t *)ws_ids;
+        float *rn = (float *)d.workspace + composed_floats(d);
+        if ((rc = launch_wave_ids16(d, ids16, stream))) return rc;
+        const bool rn_table = d.norm_byte && !concat16_norm_in_kernel(d);
+        if (rn_table && (rc = launch_rows_rnorm(d.byte_table, d.byte_rows, d.byte_dim, d.eps > 0.f ? d.eps : kBf16Eps, rn, d.dtype, stream))) return rc;
+        return launch_concat16(d, d.tokens, nullptr, ids16, N, rn_table ? rn : nullptr, d.out, d.out_row_rnorm, stream);
+    }
     int64_t *padded = d.out_ids_padded ? d.out_ids_padded : ws_ids;
     int64_t *pulled = d.out_ids_pulled ? d.out_ids_pulled : ws_ids + slots;
-    int rc;
     if ((rc = launch_tokens_to_bytes(d.tokens, N, d.ttb, d.ttb_elem_bytes, d.ttb_rows, d.bpt, padded, d.status, stream))) return rc;
     const int64_t *after = padded;
     if (d.pull_dir != MOT_PULL_NONE) {
@@ -501,8 +512,9 @@ static int launch_composed(const MotEmbedMixDesc &d, hipStream_t stream) {
     // bf16 at the shapes mot_concat16.hip takes: gather, contraction, bias and output norm are ONE kernel and u is never built
     const bool fused16 = bf && !(d.flags & MOT_FLAG_LINEAR_COMPOSED) && concat16_usable(d);
     if (fused16) {
-        if (d.norm_byte && (rc = launch_rows_rnorm(d.byte_table, d.byte_rows, Db, eps, rn, d.dtype, stream))) return rc;
-        return launch_concat16(d, d.tokens, d.ids_a, N, d.norm_byte ? rn : nullptr, d.out, d.out_row_rnorm, stream);
+        const bool rn_table = d.norm_byte && !concat16_norm_in_kernel(d);
+        if (rn_table && (rc = launch_rows_rnorm(d.byte_table, d.byte_rows, Db, eps, rn, d.dtype, stream))) return rc;
+        return launch_concat16(d, d.tokens, d.ids_a, nullptr, N, rn_table ? rn : nullptr, d.out, d.out_row_rnorm, stream);
     }
     if (one_kernel && d.norm_byte && (rc = launch_rows_rnorm(d.byte_table, d.byte_rows, Db, eps, rn, d.dtype, stream))) return rc;
     for (int64_t r0 = 0; r0 < N; r0 += kSlabRows) {

@@ -166,6 +166,27 @@ def test_bf16_concat_linear_vs_oracle(mot, path, Dt, Db, bpt, Dm, Vt, B, T, kw, 
     assert (gotg == want).mean() > 0.97
 
 
+@pytest.mark.parametrize("pull", ["left", "right", None])
+def test_bf16_gather_gemm_index_pass_outputs(mot, pull):
+    """The gather-GEMM path's own index pass (ids from the token->byte table, 16-bit in HBM): the int64 parity outputs and the pad
+    statistics are the loader's (bit-exact vs the oracle), and the result equals the same call with those ids given."""
+    Dt, Db, bpt, Dm, Vt, B, T, seed = 128, 32, 16, 512, 3000, 3, 333, 9701    # 999 tokens: ragged units and a ragged last tile
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, pull or "left", mean_valid=4.4)
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.02)
+    padded = orc.tokens_to_bytes(toks, tab.astype(np.float32))
+    pulled = {"left": orc.pull_from_left, "right": orc.pull_from_right}[pull](padded, bpt, gi.PAD, gi.EOT) if pull else padded
+    Et, Eb = bf(gi.normal_table(seed + 2, Vt, Dt)), bf(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    W = bf(gi.casted_linear_weight(seed + 4, Dm, Dt + bpt * Db))
+    counters = torch.zeros(4, dtype=torch.int64, device=DEV)
+    kw = dict(mode="concat_linear", bpt=bpt, weight=W, norm_tok=True, norm_byte=True, norm_out=True)
+    r = mot.embed_mix(dev(toks), Et, Eb, ttb=dev(tab), pull=pull, return_ids=True, counters=counters, **kw)
+    assert np.array_equal(host(r.ids_padded), padded) and np.array_equal(host(r.ids_pulled), pulled)
+    c = host(counters)
+    assert c[0] == B * T and c[1] == B * T * bpt and c[2] == (padded == gi.PAD).sum() and c[3] == (pulled == gi.PAD).sum()
+    given = mot.embed_mix(dev(toks), Et, Eb, ids_a=dev(pulled), **kw)
+    assert torch.equal(r.x, given)
+
+
 def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
     """nn.Embedding tables in bf16 (train_gpt.py:1124-1126), fp32 master weight cast per call (:185-186)."""
     from mixture_of_tokenizers_amd import modules as M
