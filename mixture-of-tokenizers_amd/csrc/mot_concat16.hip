@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
                     }
                 }
         }
-        __syncthreads();
+        c16_barrier();   // (LDS only: the first half's stores to HBM stay in flight under the second half's staging)
         constexpr int PP = NT / 2;   // 16-byte pieces of a row per lane: BN / 8 pieces over 32 lanes
         for (int lr = wave * 2 + h; lr < WMR; lr += 16) {
             const int row = half * WMR + lr;
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
                     __builtin_nontemporal_store(v[p], (bf16x8c *)(P.out + (j0 + row) * (int64_t)P.Dm + 8 * (li + 32 * p)));
             }
         }
-        __syncthreads();
+        if (half == 0) c16_barrier();   // the staging area is rewritten
         C16_STAMP(6 + half);
     }
 }
