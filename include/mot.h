@@ -323,7 +323,8 @@ typedef struct MotCrossAttnDesc {
 /*
  * Backward of mot_cross_attn_fwd (loss.backward() through the modules above, train_gpt.py:1319).  `fwd` is the
  * forward's descriptor (`out` is ignored); everything is recomputed from the inputs.  Gradients are ACCUMULATED (+=)
- * in fp32 into the given buffers.  One id tensor only (ids_b must be NULL: MOT_EUNSUPPORTED otherwise).
+ * in fp32 into the given buffers.  With two id tensors (ids_b, the add_padded_and_pulled embedding of train_gpt.py:364-372)
+ * the key / value rows are per kv position: the workspace then grows with n_tokens * bpt rows of 2 * heads * 128 floats.
  */
 typedef struct MotCrossAttnGrads {
     uint32_t struct_size;  /* sizeof(MotCrossAttnGrads) */

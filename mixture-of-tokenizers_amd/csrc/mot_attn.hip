@@ -223,7 +223,9 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
 
 
 // ==========================================================================================
-// Backward (loss.backward() through ByteMixinCrossAttn + FlexibleEmbedding, train_gpt.py:1319).  One id tensor.
+// Backward (loss.backward() through ByteMixinCrossAttn + FlexibleEmbedding, train_gpt.py:1319).  One id tensor; with two
+// (add_padded_and_pulled: xkv = norm?(E[a] + E[b]) per kv position, train_gpt.py:364-372) the "table" below has one row per kv
+// position -- same kernels, identity grouping, and the byte-table gradient comes from the SUM front-end's backward.
 //   forward recompute   q_pre = W_q xq;  k_pre, v_pre per byte-table row;  k_n = norm_head(k_pre);  y (attention)
 //   dW_p += g^T y                      gemm_tn            dy = g W_p            dense GEMM (prebuilt k-major operand)
 //   cross_attn_bwd_kernel, one wave per (token, head): softmax weights p_c across lanes (lane c holds key c),
@@ -282,8 +284,11 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     if (lane < A.bpt) {
         int64_t p = pos0 + lane;
         if (A.layout == 0) p = (((int64_t)h * A.T + t) * A.bpt + lane) / A.H;
-        int64_t row = A.ids[p];
-        if ((uint64_t)row >= (uint64_t)A.rows) row = 0;   // flagged by the forward
+        int64_t row = p;   // two id tensors: the key / value rows are per kv position
+        if (A.ids) {
+            row = A.ids[p];
+            if ((uint64_t)row >= (uint64_t)A.rows) row = 0;   // flagged by the forward
+        }
         rowv = (int)row;
     }
     auto row_at = [&](int c) { return (int64_t)__builtin_amdgcn_readlane(rowv, c); };
@@ -550,6 +555,10 @@ __global__ __launch_bounds__(kThreads) void ids_to_i32_kernel(const int64_t *__r
 }
 
 
+__global__ __launch_bounds__(kThreads) void iota_i32_kernel(int32_t *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) out[i] = (int32_t)i;
+}
+
 // workspace of the backward, in floats
 struct AttnBwdLayout {
     size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, emb, emb_bytes, total;
@@ -560,19 +569,37 @@ static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, con
     e.tokens = (const int32_t *)tokens; e.tok_table = table; e.tok_rows = rows; e.tok_dim = dim; e.model_dim = dim;
     e.norm_tok = norm; e.eps = eps; e.status = status;
 }
+// the byte-table gradient of the two-id embedding norm?(E[a] + E[b]): the SUM front-end with E as both tables, a as the "token"
+// id, b as the one "byte" id of a D-wide slot
+static void dual_bwd_desc(MotEmbedMixDesc &e, const void *ids_a32, const void *ids_b, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps,
+                          uint32_t *status) {
+    memset(&e, 0, sizeof(e));
+    e.struct_size = sizeof(e); e.dtype = MOT_F32; e.n_rows = 1; e.tokens_per_row = n; e.mode = MOT_MIX_SUM; e.bpt = 1;
+    e.id_source = MOT_IDS_GIVEN; e.ids_a = (const int64_t *)ids_b;
+    e.tokens = (const int32_t *)ids_a32; e.tok_table = table; e.tok_rows = rows; e.tok_dim = dim; e.model_dim = dim;
+    e.byte_table = table; e.byte_rows = rows; e.byte_dim = dim;
+    e.norm_out = norm; e.eps = eps; e.status = status;
+}
 static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     AttnBwdLayout L;
-    const size_t T = (size_t)d.n_tokens, HD = (size_t)d.n_heads * kHd, D = (size_t)d.dim, R = (size_t)d.byte_rows, P = T * d.bpt;
+    const size_t T = (size_t)d.n_tokens, HD = (size_t)d.n_heads * kHd, D = (size_t)d.dim, P = T * d.bpt;
+    const bool dual = d.ids_b != nullptr;
+    const size_t R = dual ? P : (size_t)d.byte_rows;   // key / value rows: per byte-table row, or per kv position
     size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
     L.q = take(T * HD); L.y = take(T * HD); L.kpre = take(R * HD); L.vpre = take(R * HD); L.kn = take(R * HD); L.vl = take(R * HD);
     L.dy = take(T * HD); L.dq = take(T * HD); L.pw = take(P * d.n_heads); L.dsw = take(P * d.n_heads); L.qrot = take(T * HD);
-    L.grp = take(group_positions_ws_ints((int64_t)P, (int64_t)R));   // byte ids of the kv positions, grouped
+    // byte ids of the kv positions, grouped -- or, per position, the identity order (2 P ints)
+    L.grp = take(dual ? 2 * P : group_positions_ws_ints((int64_t)P, (int64_t)d.byte_rows));
     L.dkn_tab = take(R * HD); L.dvl_tab = take(R * HD); L.dkv = take(R * 2 * HD); L.xkv = take(R * D); L.dxkv = take(R * D);
     L.xq = take(T * D); L.dxq = take(T * D); L.ids32 = take(P);
-    MotEmbedMixDesc e;   // scratch of the token-table embedding backward
+    MotEmbedMixDesc e;   // scratch of the token-table embedding backward and of the two-id byte-table backward
     noop_bwd_desc(e, nullptr, (int64_t)T, nullptr, d.tok_rows, (int)D, d.norm_tok, 0.f, nullptr);
     size_t a = embed_mix_bwd_workspace_bytes(e), b = 0;
+    if (dual) {
+        dual_bwd_desc(e, nullptr, nullptr, (int64_t)P, nullptr, d.byte_rows, (int)D, d.norm_byte, 0.f, nullptr);
+        b = embed_mix_bwd_workspace_bytes(e);
+    }
     L.emb_bytes = a > b ? a : b;
     L.emb = take((L.emb_bytes + 3) / 4);
     L.total = o;
@@ -587,11 +614,14 @@ static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *
 }
 
 int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr, hipStream_t stream) {
-    const int64_t T = d.n_tokens, R = d.byte_rows, P = T * d.bpt;
+    const int64_t T = d.n_tokens, P = T * d.bpt;
+    const bool dual = d.ids_b != nullptr;          // kv embedding norm?(E[a] + E[b]): key / value rows per kv position, not per table row
+    const int64_t R = dual ? P : d.byte_rows;
     const int H = d.n_heads, HD = H * kHd, D = d.dim;
     const AttnBwdLayout L = attn_bwd_layout(d);
     if (!d.workspace || d.workspace_bytes < L.total * 4)
         return set_error(MOT_EWORKSPACE, "cross_attn_bwd: needs %zu workspace bytes, got %zu", L.total * 4, d.workspace_bytes);
+    if (dual && R * (int64_t)HD >= 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "cross_attn_bwd: two id tensors at %lld kv positions are not built", (long long)P);
     float *ws = (float *)d.workspace;
     float *q = ws + L.q, *y = ws + L.y, *kpre = ws + L.kpre, *vpre = ws + L.vpre, *kn = ws + L.kn, *vl = ws + L.vl, *dy = ws + L.dy, *dq = ws + L.dq;
     float *pw = ws + L.pw, *dsw = ws + L.dsw, *qrot = ws + L.qrot, *dkn_tab = ws + L.dkn_tab, *dvl_tab = ws + L.dvl_tab, *dkv = ws + L.dkv;
@@ -601,7 +631,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
     const float *g_out = (const float *)gr.grad_out;
     int rc;
-    hipLaunchKernelGGL(ids_to_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, d.ids_a, P, R, ids32);
+    hipLaunchKernelGGL(ids_to_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, d.ids_a, P, (int64_t)d.byte_rows, ids32);
     if ((rc = check_launch("ids_to_i32"))) return rc;
     if ((rc = launch_zero_words(dkn_tab, (int64_t)R * HD, stream))) return rc;
     if ((rc = launch_zero_words(dvl_tab, (int64_t)R * HD, stream))) return rc;
@@ -616,16 +646,21 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         have_xq = true;
     }
     const float *kv_w = (const float *)d.kv_w;
-    // the normalised byte-table rows (also the operand of dW_kv below), projected by the plain dense kernel
-    hipLaunchKernelGGL(rows_norm_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, R, D, d.norm_byte, eps, xkv);
-    if ((rc = check_launch("rows_norm_kernel"))) return rc;
+    // the normalised byte-table rows -- or the normalised per-position sums E[a] + E[b] -- (also the operand of dW_kv below),
+    // projected by the plain dense kernel
+    if (dual) {
+        if ((rc = launch_gather_rows(d.ids_a, d.ids_b, 8, P, d.byte_table, d.byte_rows, D, d.norm_byte, eps, nullptr, xkv, d.status, MOT_F32, stream))) return rc;
+    } else {
+        hipLaunchKernelGGL(rows_norm_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, R, D, d.norm_byte, eps, xkv);
+        if ((rc = check_launch("rows_norm_kernel"))) return rc;
+    }
     if ((rc = launch_gemm_rows(xkv, D, R, kv_w, D, D, HD, kpre, HD, true, stream))) return rc;
     if ((rc = launch_gemm_rows(xkv, D, R, kv_w + (size_t)HD * D, D, D, HD, vpre, HD, true, stream))) return rc;
     const int64_t kvw = R * H;
     hipLaunchKernelGGL(kv_norm_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kpre, vpre, R, H, d.lambda_factor, eps, kn, vl);
     if ((rc = check_launch("kv_norm_kernel"))) return rc;
     AttnArgs A;
-    A.q = q; A.y = y; A.kt = kn; A.vt = vl; A.ids = d.ids_a; A.rows = R; A.T = T; A.bpt = d.bpt; A.H = H;
+    A.q = q; A.y = y; A.kt = kn; A.vt = vl; A.ids = dual ? nullptr : d.ids_a; A.rows = R; A.T = T; A.bpt = d.bpt; A.H = H;
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
     const int64_t waves = T * H;
     if (!d.saved_qy) {
@@ -637,7 +672,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, stream))) return rc;
     // ---- attention
     AttnBwdArgs B;
-    B.q_pre = q; B.dy = dy; B.kn = kn; B.vpre = vpre; B.lambda = d.lambda_factor; B.ids = d.ids_a; B.rows = R; B.T = T; B.bpt = d.bpt; B.H = H;
+    B.q_pre = q; B.dy = dy; B.kn = kn; B.vpre = vpre; B.lambda = d.lambda_factor; B.ids = dual ? nullptr : d.ids_a; B.rows = R; B.T = T; B.bpt = d.bpt; B.H = H;
     B.layout = d.head_layout; B.cos_q = d.cos_q; B.sin_q = d.sin_q; B.cos_k = d.cos_k; B.sin_k = d.sin_k; B.eps = eps;
     B.dq = dq; B.pw = pw; B.dsw = dsw; B.qrot = qrot;
     hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
@@ -645,7 +680,12 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     // ---- per byte-table row: the sums over the kv positions of every byte id, from the grouped positions
     {
         const int32_t *pos_sorted, *id_sorted;
-        if ((rc = launch_group_positions(ids32, P, R, (int32_t *)(ws + L.grp), &pos_sorted, &id_sorted, nullptr, stream))) return rc;
+        if (dual) {   // every kv position is its own row: the identity order, runs of one
+            int32_t *iota = (int32_t *)(ws + L.grp);
+            hipLaunchKernelGGL(iota_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, iota, P);
+            if ((rc = check_launch("iota_i32_kernel"))) return rc;
+            pos_sorted = id_sorted = iota;
+        } else if ((rc = launch_group_positions(ids32, P, R, (int32_t *)(ws + L.grp), &pos_sorted, &id_sorted, nullptr, stream))) return rc;
         AttnRowsArgs Rw;
         Rw.pw = pw; Rw.dsw = dsw; Rw.dy = dy; Rw.qrot = qrot; Rw.cos_k = d.cos_k; Rw.sin_k = d.sin_k;
         Rw.pos_sorted = pos_sorted; Rw.id_sorted = id_sorted; Rw.P = P; Rw.T = T; Rw.bpt = d.bpt; Rw.H = H; Rw.layout = d.head_layout;
@@ -672,7 +712,17 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     if ((rc = check_launch("kv_table_bwd_kernel"))) return rc;
     // ---- kv_w and the byte table (xkv: the normalised table rows built for the recompute above)
     if (gr.d_kv_w && (rc = launch_gemm_tn(dkv, 2 * HD, 2 * HD, xkv, D, D, R, (float *)gr.d_kv_w, D, stream))) return rc;
-    if (gr.d_byte_table) {
+    if (gr.d_byte_table && dual) {
+        // d(E[a] + E[b]) = norm^T(dxkv), added to the table at rows a and b: the SUM front-end's backward with the byte table in
+        // both roles (its token-table and byte-table gradients are the same buffer; both are accumulated with atomic adds)
+        if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;
+        dual_bwd_desc(ed, ids32, d.ids_b, P, d.byte_table, d.byte_rows, D, d.norm_byte, eps, d.status);
+        ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
+        eg.grad_out = dxkv; eg.d_tok_table = gr.d_byte_table; eg.d_byte_table = gr.d_byte_table;
+        if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
+        memset(&eg, 0, sizeof(eg));
+        eg.struct_size = sizeof(eg);
+    } else if (gr.d_byte_table) {
         if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;   // kv_w as [2 HD, D]
         hipLaunchKernelGGL(byte_rows_bwd_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, dxkv, R, D,
                            d.norm_byte, eps, (float *)gr.d_byte_table);

@@ -299,7 +299,6 @@ int mot_cross_attn_bwd(const MotCrossAttnDesc *desc, const MotCrossAttnGrads *gr
     if (!d.out) d.out = (void *)grads->grad_out;   // the forward validator wants a non-null `out`; the backward never writes it
     int rc = validate_cross_attn(&d);
     if (rc) return rc;
-    if (d.ids_b) return set_error(MOT_EUNSUPPORTED, "cross_attn_bwd: the two-id-tensor embedding (norm(E[a] + E[b])) is forward-only");
     if (!grads->grad_out) return set_error(MOT_EINVAL, "cross_attn_bwd: grad_out missing");
     if (d.n_tokens == 0) return MOT_OK;
     return launch_cross_attn_bwd(d, *grads, (hipStream_t)stream);
