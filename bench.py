@@ -57,8 +57,8 @@ WORKLOADS = {
 }
 F32_MFMA_PEAK_TFLOPS = 157.3  # dense fp32 matrix peak, MI355X_MICROARCH.md
 # sources whose change invalidates the committed PMC traffic figure of the fused SUM kernel
-TRAFFIC_SOURCES = ("include/mot.h", "mixture-of-tokenizers_amd/csrc/mot_embed.hip", "mixture-of-tokenizers_amd/csrc/mot_mix.hpp",
-                   "mixture-of-tokenizers_amd/csrc/mot_tile.hpp", "mixture-of-tokenizers_amd/csrc/mot_internal.hpp")
+TRAFFIC_SOURCES = ("mixture-of-tokenizers_amd/csrc/mot_embed.hip", "mixture-of-tokenizers_amd/csrc/mot_wave.hpp",
+                   "mixture-of-tokenizers_amd/csrc/mot_mix.hpp", "mixture-of-tokenizers_amd/csrc/mot_tile.hpp")   # what the fused kernel is compiled from
 
 
 def source_sha16() -> str:

@@ -566,10 +566,7 @@ static int launch_mean_lds(MixArgs A, const MotEmbedMixDesc &d, int slice_cols, 
     A.T = N;                                                  // flat token addressing (rows are independent without a pull)
     const size_t lds = (size_t)d.byte_rows * slice_cols * sizeof(T);
     static std::atomic<uint64_t> lds_ok{0};   // per-device bits
-#ifndef MOT_VAR_MEANU
-#define MOT_VAR_MEANU 4
-#endif
-    constexpr int kMeanU = MOT_VAR_MEANU;   // token-row slices in flight per wave
+    constexpr int kMeanU = 4;   // token-row slices in flight per wave (8 spilled before the loop was pipelined; no effect since)
     if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU>, lds_ok, "embed_mean_lds_kernel")) return rc_lds;
     hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
     return check_launch("embed_mean_lds_kernel");
