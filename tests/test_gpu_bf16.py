@@ -187,6 +187,47 @@ def test_bf16_gather_gemm_index_pass_outputs(mot, pull):
     assert torch.equal(r.x, given)
 
 
+def test_bf16_concat_full_size_c2(mot):
+    """BASELINE config 2 in its concat form at full size (64 x 1024 tokens, GPT-2 vocab and the real token->byte table, token dim 256,
+    byte dim 32, bpt 16, d 768), production dtype: the gather-GEMM kernel over all 512 of its 128-token tiles.  Oracle comparison on 4
+    of the 64 rows (rows are independent), size-independent properties on all of them."""
+    B, T, bpt, Dt, Db, Dm = 64, 1024, 16, 256, 32, 768
+    tab = gi.widen_left_pad(gi.load_real_ttb8(), bpt)
+    toks = gi.fineweb_like_tokens(12345, B, T)
+    Et, Eb = orc.bf16_round(gi.normal_table(1, gi.GPT2_VOCAB, Dt)), orc.bf16_round(gi.normal_table(2, gi.BYTE_VOCAB, Db))
+    W = orc.bf16_round(gi.casted_linear_weight(3, Dm, Dt + bpt * Db))
+    b16 = lambda a: dev(a).bfloat16()
+    kw = dict(mode="concat_linear", bpt=bpt, weight=b16(W), norm_tok=True, norm_byte=True, norm_out=True)
+    r = mot.embed_mix(dev(toks), b16(Et), b16(Eb), ttb=dev(tab), pull="left", return_ids=True, **kw)
+    mot.check_status()
+    rows = np.arange(0, B, 16)
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks[rows], tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    np.testing.assert_array_equal(host(r.ids_pulled[rows]), pulled)
+    orc.set_eps(2.0 ** -7); orc.set_round_segments_bf16(True)
+    try:
+        okw = dict(mode="concat_linear", bpt=bpt, weight=W.astype(np.float64), dtype=np.float64, norm_tok=True, norm_byte=True)
+        ref = orc.embed_mix(toks[rows], pulled, None, Et.astype(np.float64), Eb.astype(np.float64), norm_out=True, **okw)
+        y = orc.embed_mix(toks[rows], pulled, None, Et.astype(np.float64), Eb.astype(np.float64), norm_out=False, **okw)
+    finally:
+        orc.set_eps(0.0); orc.set_round_segments_bf16(False)
+    got, want = host(r.x[rows].float()), orc.bf16_round(ref)
+    noise = np.maximum(5e-4, float(np.abs(W).max()) * 2.0 ** -5 / np.sqrt((y ** 2).mean(-1, keepdims=True) + 2.0 ** -7))   # see the test above
+    far = np.abs(got.astype(np.float64) - want) > noise
+    assert ulps(got, want)[far].max(initial=0) <= 2 and (got == want).mean() > 0.97
+    x = r.x
+    assert bool(torch.isfinite(x.float()).all())
+    ms = (x.double() ** 2).mean(-1)
+    # every row is rms-normalised with the bf16 epsilon: mean(x^2) = m / (m + 2^-7) for m = mean(y^2), here m ~ 0.25
+    assert 0.9 < float(ms.min()) and float(ms.max()) < 1 + 2.0 ** -6
+    # positions with identical (token, pulled bytes) give identical outputs, whatever tile and lane they land in
+    key = torch.cat([dev(toks).view(B, T, 1).long(), r.ids_pulled.view(B, T, bpt)], -1).view(-1, bpt + 1)
+    uniq, inv = torch.unique(key, dim=0, return_inverse=True)
+    first = torch.zeros(uniq.shape[0], dtype=torch.long, device=DEV).scatter_(0, inv, torch.arange(inv.numel(), device=DEV))
+    assert torch.equal(x.view(-1, Dm), x.view(-1, Dm)[first[inv]])
+    # and the module-level path (ids precomputed as the reference loader emits) is bitwise the same
+    assert torch.equal(x, mot.embed_mix(dev(toks), b16(Et), b16(Eb), ids_a=r.ids_pulled, **kw))
+
+
 def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
     """nn.Embedding tables in bf16 (train_gpt.py:1124-1126), fp32 master weight cast per call (:185-186)."""
     from mixture_of_tokenizers_amd import modules as M
