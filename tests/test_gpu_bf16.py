@@ -228,6 +228,32 @@ def test_bf16_concat_full_size_c2(mot):
     assert torch.equal(x, mot.embed_mix(dev(toks), b16(Et), b16(Eb), ids_a=r.ids_pulled, **kw))
 
 
+def test_bf16_gather_gemm_is_capturable_in_a_hip_graph(mot):
+    """The bf16 concat + linear forward is two kernels (the wave-local index pass, the gather-GEMM) and no memset, allocation or
+    sync: capture, change the batch and the weight in place, replay, compare with eager."""
+    bpt, Vt, B, T, Dt, Db, Dm = 16, 2048, 4, 300, 256, 32, 768
+    tab = dev(gi.synth_ttb(131, Vt, bpt, "left"))
+    Et, Eb = bf(gi.normal_table(132, Vt, Dt)), bf(gi.normal_table(133, gi.BYTE_VOCAB, Db))
+    W = bf(gi.casted_linear_weight(134, Dm, Dt + bpt * Db))
+    toks = dev(gi.fineweb_like_tokens(135, B, T, vocab=Vt, eot_p=0.01))
+    out = torch.empty((B, T, Dm), device=DEV, dtype=torch.bfloat16)
+    kw = dict(mode="concat_linear", bpt=bpt, ttb=tab, pull="left", weight=W, norm_tok=True, norm_byte=True, norm_out=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        mot.embed_mix(toks, Et, Eb, out=out, **kw)          # warm-up on the capture stream (allocates the workspace)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        mot.embed_mix(toks, Et, Eb, out=out, **kw)
+    toks.copy_(dev(gi.fineweb_like_tokens(136, B, T, vocab=Vt, eot_p=0.01)))
+    W.mul_(0.5)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, mot.embed_mix(toks, Et, Eb, **kw))
+
+
 def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
     """nn.Embedding tables in bf16 (train_gpt.py:1124-1126), fp32 master weight cast per call (:185-186)."""
     from mixture_of_tokenizers_amd import modules as M
