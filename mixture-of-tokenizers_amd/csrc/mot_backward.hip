@@ -1736,15 +1736,15 @@ static int launch_widen(const void *src, size_t n, float *dst, hipStream_t strea
 
 // du = dy . W of the bf16 backward on the bf16 MFMA (what autograd does for bf16 parameters): dy rounded to bf16,
 // W^T as the [K, Dm] "weight" of the forward bf16 kernel in dense-row mode, du widened back for the scatter stage.
-// Scratch behind the fp32 layouts, in bytes: [dy16: N*Dm*2][wt16: K*Dm*2][dyT: N*Dm*2][uT: N*K*2].
-struct Du16Layout { size_t dy16, wt16, dyT, uT, total; };
+// Scratch behind the fp32 layouts, in bytes: [dy16: N*Dm*2][wt16: K*Dm*2][u16: N*K*2].
+struct Du16Layout { size_t dy16, wt16, uT, total; };
 static Du16Layout du16_layout(const MotEmbedMixDesc &d) {
     Du16Layout U;
     const size_t N = (size_t)(d.n_rows * d.tokens_per_row), K = (size_t)d.tok_dim + (size_t)d.bpt * d.byte_dim, Dm = (size_t)d.model_dim;
     size_t o = 0;
     auto take = [&](size_t bytes) { size_t at = o; o += (bytes + 255) & ~(size_t)255; return at; };
     U.dy16 = take(N * Dm * 2); U.wt16 = take(K * Dm * 2);
-    U.dyT = take(N * Dm * 2); U.uT = take(N * K * 2);   // token-major -> token-minor copies for the dW GEMM
+    U.uT = take(N * K * 2);   // the concat operand in bf16, row-major (dW)
     U.total = o;
     return U;
 }
@@ -1767,32 +1767,29 @@ __global__ __launch_bounds__(kThreads) void narrow_kernel(const float *__restric
     }
 }
 
-// dst[c][r] = bf16(src[r][c])  (fp32 rows x cols -> bf16 cols x rows): the token-minor operands of the dW GEMM
-__global__ __launch_bounds__(kThreads) void narrow_transpose_kernel(const float *__restrict__ src, int64_t rows, int cols, int ld, __bf16 *__restrict__ dst) {
-    __shared__ float tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    const int64_t r0 = (int64_t)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
-    for (int r = ty; r < 32; r += 8)
-        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(r0 + r) * ld + c0 + tx] : 0.f;
-    __syncthreads();
-    for (int c = ty; c < 32; c += 8)
-        if (c0 + c < cols && r0 + tx < rows) dst[(int64_t)(c0 + c) * rows + r0 + tx] = (__bf16)tile[tx][c];
-}
 
-// C[m][n] += sum_k A[m][k] * B[n][k]   (A: M x Kc, B: Nn x Kc, both bf16 with k contiguous; C fp32, leading dimension ldc)
-// on v_mfma_f32_32x32x16_bf16, split over k: blockIdx.z takes k in [z*kper, (z+1)*kper) and adds its partial tile with
-// float atomics (128-byte contiguous segments).  Workgroup tile 128 x 128, 4 waves as 2 x 2, each 64 x 64; K step 32,
-// LDS rows of 64 data + 16 pad bytes, double buffered.  Used for dW = dy^T u with k = the token index.
+// C[m][k] += sum_n A[n][m] * B[n][k]   (A: rows x M, B: rows x Kc, both bf16 ROW-major as the forward and dy_kernel leave them;
+// C fp32, leading dimension ldc) on v_mfma_f32_32x32x16_bf16: dW = dy^T u with the token index as the contraction index.
+// Both MFMA operands want 8 consecutive CONTRACTION elements per lane, i.e. a column of the row-major tiles: the tiles go into
+// LDS as they are (64 token rows x 128 columns, rows padded to 320 bytes) and are read back with ds_read_b64_tr_b16, the
+// transposing LDS read of gfx950 -- a 16-lane group fetches 4 rows x 16 columns and every lane receives ONE column's 4 rows;
+// two reads make a lane's 8 contraction elements.  (Round 1 transposed dy and u in HBM first -- narrow_transpose /
+// transpose_bf16, 0.2 ms at 65 536 x 768 -- and contracted the token-minor copies: 0.30 ms more, with 85-fold split-k atomics.)
+// With 320-byte rows the four rows of a read sit 80 dwords apart: a 32-lane half (two groups, 32 columns) covers all 64 banks once.
+// Workgroup tile 128 x 128, 4 waves as 2 x 2, each 64 x 64; contraction split over blockIdx.z; partial tiles are added with
+// float atomics (128-byte contiguous segments).  128 x 128 keeps the split count -- and with it the atomic volume
+// (splits x M x Kc x 4 bytes) -- at 7 for 768 x 768 on 256 CUs.
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(kThreads) void gemm_nt_bf16_splitk_kernel(const __bf16 *__restrict__ A_, int M, const __bf16 *__restrict__ B_, int Nn, int64_t Kc,
-                                                                       int64_t kper, float *__restrict__ C, int ldc) {
-    constexpr int RB = 80;   // bytes per staged row
-    __shared__ __attribute__((aligned(16))) char lA[2][128 * RB], lB[2][128 * RB];
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+constexpr int kTnRows = 64, kTnLd = 160;   // token rows per step; elements per staged row (128 data + 32 pad)
+__global__ __launch_bounds__(kThreads) void gemm_tn_bf16_kernel(const __bf16 *__restrict__ A_, int lda, int M, const __bf16 *__restrict__ B_, int ldb, int Kc,
+                                                                int64_t rows, int64_t rper, float *__restrict__ C, int ldc) {
+    extern __shared__ __attribute__((aligned(16))) __bf16 lds_tn[];   // [2][A | B][kTnRows][kTnLd]
+    constexpr int kTile = kTnRows * kTnLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
-    const int m0 = blockIdx.x * 128, n0 = blockIdx.y * 128;
-    const int64_t k_lo = (int64_t)blockIdx.z * kper, k_hi = min(Kc, k_lo + kper);
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int m0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
+    const int64_t r_lo = (int64_t)blockIdx.z * rper, r_hi = min(rows, r_lo + rper);
+    const int wm = (wave >> 1) * 64, wk = (wave & 1) * 64;
     f32x16b acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1800,42 +1797,57 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_bf16_splitk_kernel(const __b
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // staging: 128 rows x 4 pieces of 16 bytes per operand = 512 pieces -> 2 per thread
-    bf16x8w ra[2], rb[2];
-    auto load_stage = [&](int64_t k) {
+    // staging: 64 rows x 16 pieces of 16 bytes per operand = 1024 pieces -> 4 per thread (16 lanes read one 256-byte row segment)
+    bf16x8w ra[4], rb[4];
+    auto load_stage = [&](int64_t r0) {
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int q = p * kThreads + tid, row = q >> 2, c = q & 3;
-            const int64_t kk = k + 8 * c;
+        for (int p = 0; p < 4; ++p) {
+            const int q = p * kThreads + tid, row = q >> 4, c = (q & 15) * 8;
             ra[p] = (bf16x8w)((__bf16)0.f); rb[p] = (bf16x8w)((__bf16)0.f);
-            if (kk < k_hi) {   // Kc and the k split are multiples of 8: a piece is wholly inside or outside
-                if (m0 + row < M) ra[p] = *(const bf16x8w *)(A_ + (int64_t)(m0 + row) * Kc + kk);
-                if (n0 + row < Nn) rb[p] = *(const bf16x8w *)(B_ + (int64_t)(n0 + row) * Kc + kk);
+            if (r0 + row < r_hi) {   // M, Kc, lda, ldb are multiples of 8: a piece is wholly inside or outside
+                if (m0 + c < M) ra[p] = *(const bf16x8w *)(A_ + (r0 + row) * lda + m0 + c);
+                if (k0 + c < Kc) rb[p] = *(const bf16x8w *)(B_ + (r0 + row) * ldb + k0 + c);
             }
         }
     };
     auto store_stage = [&](int buf) {
+        __bf16 *sA = lds_tn + buf * 2 * kTile, *sB = sA + kTile;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int q = p * kThreads + tid, row = q >> 2, c = q & 3;
-            *(bf16x8w *)(&lA[buf][row * RB + 16 * c]) = ra[p];
-            *(bf16x8w *)(&lB[buf][row * RB + 16 * c]) = rb[p];
+        for (int p = 0; p < 4; ++p) {
+            const int q = p * kThreads + tid, row = q >> 4, c = (q & 15) * 8;
+            *(bf16x8w *)(sA + row * kTnLd + c) = ra[p];
+            *(bf16x8w *)(sB + row * kTnLd + c) = rb[p];
         }
     };
-    load_stage(k_lo);
-    store_stage(0);
+    // transposed fragment: lane 4 q + p of a 16-lane group g addresses row (r0 + q), columns c0 + 4 p .. + 3 of the group's 4 x 16 block;
+    // lane i of the group receives column c0 + i.  Group g: contraction half h = g >> 1, columns 16 (g & 1) .. + 15 of the 32-wide tile.
+    const int grp = lane >> 4, gi = lane & 15;
+    const int tr_off = ((gi >> 2) + 8 * (grp >> 1)) * kTnLd + 16 * (grp & 1) + 4 * (gi & 3);   // elements, inside a 16-row x 32-column operand block
+    auto frag = [&](const __bf16 *tile, int s16, int col0) {   // rows 16 s16 .. + 15 (contraction), columns col0 .. + 31
+        const __bf16 *p = tile + (16 * s16) * kTnLd + col0 + tr_off;
+        const s16x4w lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w *)p);
+        const s16x4w hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4w *)(p + 4 * kTnLd));
+        typedef short s16x8w __attribute__((ext_vector_type(8)));
+        const s16x8w v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        return __builtin_bit_cast(bf16x8w, v);
+    };
+    if (r_lo < r_hi) {
+        load_stage(r_lo);
+        store_stage(0);
+    }
     __syncthreads();
     int buf = 0;
-    for (int64_t k = k_lo; k < k_hi; k += 32, buf ^= 1) {
-        const bool more = k + 32 < k_hi;
-        if (more) load_stage(k + 32);
+    for (int64_t r0 = r_lo; r0 < r_hi; r0 += kTnRows, buf ^= 1) {
+        const bool more = r0 + kTnRows < r_hi;
+        if (more) load_stage(r0 + kTnRows);
+        const __bf16 *sA = lds_tn + buf * 2 * kTile, *sB = sA + kTile;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int s16 = 0; s16 < kTnRows / 16; ++s16) {
             bf16x8w af[2], bf[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = *(const bf16x8w *)(&lA[buf][(wm + a * 32 + li) * RB + 32 * ks + 16 * h]);
+            for (int a = 0; a < 2; ++a) af[a] = frag(sA, s16, wm + 32 * a);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) bf[b] = *(const bf16x8w *)(&lB[buf][(wn + b * 32 + li) * RB + 32 * ks + 16 * h]);
+            for (int b = 0; b < 2; ++b) bf[b] = frag(sB, s16, wk + 32 * b);
 #pragma unroll
             for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -1844,27 +1856,33 @@ __global__ __launch_bounds__(kThreads) void gemm_nt_bf16_splitk_kernel(const __b
         if (more) store_stage(buf ^ 1);
         __syncthreads();
     }
-    // D[i][j]: lane -> j (B row = output column n), registers -> i (A row = output row m)
+    // D[i][j]: lane -> j (B column = output column k), registers -> i (A column = output row m)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + b * 32 + li;
-                if (m < M && n < Nn) atomicAdd(C + (int64_t)m * ldc + n, acc[a][b][r]);
+                const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = k0 + wk + b * 32 + li;
+                if (m < M && k < Kc) atomicAdd(C + (int64_t)m * ldc + k, acc[a][b][r]);
             }
 }
 
-static int launch_gemm_nt_bf16(const __bf16 *A_, int M, const __bf16 *B_, int Nn, int64_t Kc, float *C, int ldc, hipStream_t stream) {
-    if (M <= 0 || Nn <= 0 || Kc <= 0) return MOT_OK;
-    const int gx = (M + 127) / 128, gy = (Nn + 127) / 128;
-    int64_t splits = (1024 + gx * gy - 1) / (gx * gy);
-    int64_t kper = ((Kc + splits - 1) / splits + 31) / 32 * 32;
-    if (kper < 512) kper = 512;
-    splits = (Kc + kper - 1) / kper;
-    hipLaunchKernelGGL(gemm_nt_bf16_splitk_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits), dim3(kThreads), 0, stream, A_, M, B_, Nn, Kc, kper, C, ldc);
-    return check_launch("gemm_nt_bf16_splitk_kernel");
+// A, B: 16-byte aligned, lda / ldb / M / Kc multiples of 8
+static int launch_gemm_tn_bf16(const __bf16 *A_, int lda, int M, const __bf16 *B_, int ldb, int Kc, int64_t rows, float *C, int ldc, hipStream_t stream) {
+    if (M <= 0 || Kc <= 0 || rows <= 0) return MOT_OK;
+    const int gx = (M + 127) / 128, gy = (Kc + 127) / 128;
+    int64_t splits = 256 / (gx * gy);   // one workgroup per CU; fewer splits = less atomic traffic
+    if (splits < 1) splits = 1;
+    int64_t rper = ((rows + splits - 1) / splits + kTnRows - 1) / kTnRows * kTnRows;
+    if (rper < 4 * kTnRows) rper = 4 * kTnRows;
+    splits = (rows + rper - 1) / rper;
+    const size_t lds = (size_t)4 * kTnRows * kTnLd * sizeof(__bf16);
+    static std::atomic<uint64_t> lds_ok{0};
+    if (int rc = ensure_max_dyn_lds((const void *)gemm_tn_bf16_kernel, lds_ok, "gemm_tn_bf16_kernel")) return rc;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits), dim3(kThreads), lds, stream, A_, lda, M, B_, ldb, Kc, rows, rper,
+                       C, ldc);
+    return check_launch("gemm_tn_bf16_kernel");
 }
 
 // dst[c][r] = src[r][c]   (rows x cols -> cols x rows), bf16, 32 x 32 tiles through LDS
@@ -1891,9 +1909,10 @@ size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
 
 // `w16` / `ws16` (optional): the bf16 weight and the Du16Layout scratch -- then du and dW run on the bf16 MFMA; `g16` / `x16`
 // (optional with them): the bf16 upstream gradient and forward output -- then dy is produced in bf16 directly and
-// gr.grad_out / d.out (fp32) are never read
+// gr.grad_out / d.out (fp32) are never read; `d16`: the caller's descriptor with the bf16 tables (the concat operand of dW is then
+// gathered from them directly, as the forward's was)
 static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream, const void *w16 = nullptr,
-                                       char *ws16 = nullptr, const void *g16 = nullptr, const void *x16 = nullptr) {
+                                       char *ws16 = nullptr, const void *g16 = nullptr, const void *x16 = nullptr, const MotEmbedMixDesc *d16 = nullptr) {
     if (d.id_source != MOT_IDS_GIVEN) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: pass the byte ids the forward returned (MOT_IDS_GIVEN)");
     if (!gr.d_weight) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: d_weight missing");
     if (d.norm_out && (!d.out || !d.out_row_rnorm)) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: needs the forward's out and out_row_rnorm");
@@ -1931,7 +1950,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
             if (d.workspace_bytes < off + du16_layout(d).total)
                 return set_error(MOT_EWORKSPACE, "embed_mix_bwd: needs %zu workspace bytes, got %zu", off + du16_layout(d).total, d.workspace_bytes);
             return launch_embed_mix_bwd_linear(d32, g32, stream, d.weight, (char *)d.workspace + off, dy_in_bf16 ? gr.grad_out : nullptr,
-                                               dy_in_bf16 ? d.out : nullptr);
+                                               dy_in_bf16 ? d.out : nullptr, &d);
         }
         return launch_embed_mix_bwd_linear(d32, g32, stream);
     }
@@ -1940,7 +1959,7 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     float *ws = (float *)d.workspace;
     float *rn = ws + L.rnorm, *dy = ws + L.dy, *du = ws + L.du, *utok = ws + L.utok, *ubyte = ws + L.ubyte, *wk = ws + L.wk, *byte0 = ws + L.byte0;
     int32_t *iota = (int32_t *)(ws + L.iota), *sort_ints = (int32_t *)(ws + L.sort);
-    (void)wk; (void)byte0;   // slots of the layout the fp32 du product no longer uses
+    (void)wk; (void)byte0; (void)ubyte;   // slots of the layout the fp32 du product no longer uses (u is built in place: utok .. ubyte)
     const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
     int rc;
     // 1. dy
@@ -1972,32 +1991,43 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     (void)blk;
     const int tok_lo = d.bytes_first ? nbk : 0, byte_lo = d.bytes_first ? 0 : Dt;
     float *dW = (float *)gr.d_weight;
-    if (w16) {   // two dense seam tensors (the bf16 contraction takes token-minor copies of each)
-        if ((rc = launch_gather_rows(d.tokens, nullptr, 4, N, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, d.scale_tok, utok, d.status, MOT_F32, stream))) return rc;
-        if ((rc = launch_gather_rows(d.ids_a, d.ids_b, 8, N * d.bpt, d.byte_table, d.byte_rows, d.byte_dim, d.norm_byte, eps, d.scale_byte, ubyte, d.status,
-                                     MOT_F32, stream))) return rc;
-    } else {     // fp32: the concat operand u [N, K] itself, in the two (adjacent) scratch regions, so dW is ONE contraction
+    // (w16: the concat operand goes straight to bf16, below)
+    if (!w16) {  // fp32: the concat operand u [N, K] itself, in the two (adjacent) scratch regions, so dW is ONE contraction
         if ((rc = launch_gather_rows_placed(d.tokens, nullptr, 4, N, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, d.scale_tok, utok + tok_lo, 1, K,
                                             d.status, kStatusTokenOor, MOT_F32, stream))) return rc;
         if ((rc = launch_gather_rows_placed(d.ids_a, d.ids_b, 8, N * d.bpt, d.byte_table, d.byte_rows, d.byte_dim, d.norm_byte, eps, d.scale_byte,
                                             utok + byte_lo, d.bpt, K, d.status, kStatusByteOor, MOT_F32, stream))) return rc;
-    }
-    if (w16) {
-        // 2'. dW on the bf16 MFMA: token-minor bf16 copies of dy and of the two parts of u, contraction over the tokens
-        const Du16Layout U = du16_layout(d);
-        __bf16 *dyT = (__bf16 *)(ws16 + U.dyT), *uT = (__bf16 *)(ws16 + U.uT);
-        const unsigned gxN = (unsigned)((N + 31) / 32);
-        if (dy16p)
-            hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((Dm + 31) / 32), gxN), dim3(kThreads), 0, stream, dy16p, (int)N, Dm, dyT);
-        else
-            hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream, dyp, N, Dm, Dm, dyT);
-        hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((Dt + 31) / 32)), dim3(kThreads), 0, stream, utok, N, Dt, Dt, uT);
-        hipLaunchKernelGGL(narrow_transpose_kernel, dim3(gxN, (unsigned)((nbk + 31) / 32)), dim3(kThreads), 0, stream, ubyte, N, nbk, nbk, uT + (size_t)Dt * N);
-        if ((rc = check_launch("narrow_transpose_kernel"))) return rc;
-        if ((rc = launch_gemm_nt_bf16(dyT, Dm, uT, Dt, N, dW + tok_lo, K, stream))) return rc;
-        if ((rc = launch_gemm_nt_bf16(dyT, Dm, uT + (size_t)Dt * N, nbk, N, dW + byte_lo, K, stream))) return rc;
-    } else {
         if ((rc = launch_gemm_tn(dyp, Dm, Dm, utok, K, K, N, dW, K, stream))) return rc;
+    } else {
+        // 2'. dW on the bf16 MFMA: dy [N, Dm] and u [N, K] in bf16, ROW-major as they are, contracted over the tokens by
+        // gemm_tn_bf16_kernel (transposing LDS reads).  u is the forward's operand: gathered from the bf16 tables by the forward's
+        // own concat_rows_kernel when that applies (one id tensor, no learned scalars, 16-byte pieces), else gathered in fp32 from
+        // the widened tables and narrowed.
+        const Du16Layout U = du16_layout(d);
+        __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16), *u16 = (__bf16 *)(ws16 + U.uT);
+        const __bf16 *dyr = dy16p;
+        if (!dyr) {
+            size_t nb = ((size_t)N * Dm / 8 + kThreads) / kThreads;
+            if (nb > 4096) nb = 4096;
+            hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dyp, (int64_t)N * Dm, dy16);
+            if ((rc = check_launch("narrow_kernel"))) return rc;
+            dyr = dy16;
+        }
+        if (d16 && !d.ids_b && !d.scale_tok && !d.scale_byte && (Dt & 7) == 0 && (d.byte_dim & 7) == 0) {
+            if (d.norm_byte && (rc = launch_rows_rnorm(d16->byte_table, d.byte_rows, d.byte_dim, eps, rn, MOT_BF16, stream))) return rc;
+            if ((rc = launch_concat_rows(d.tokens, d.ids_a, N, d16->tok_table, d.tok_rows, Dt, d16->byte_table, d.byte_rows, d.byte_dim, d.bpt, d.norm_tok,
+                                         d.norm_byte ? rn : nullptr, eps, u16, K, tok_lo, byte_lo, d.status, MOT_BF16, stream))) return rc;
+        } else {
+            if ((rc = launch_gather_rows_placed(d.tokens, nullptr, 4, N, d.tok_table, d.tok_rows, Dt, d.norm_tok, eps, d.scale_tok, utok + tok_lo, 1, K,
+                                                d.status, kStatusTokenOor, MOT_F32, stream))) return rc;
+            if ((rc = launch_gather_rows_placed(d.ids_a, d.ids_b, 8, N * d.bpt, d.byte_table, d.byte_rows, d.byte_dim, d.norm_byte, eps, d.scale_byte,
+                                                utok + byte_lo, d.bpt, K, d.status, kStatusByteOor, MOT_F32, stream))) return rc;
+            size_t nb = ((size_t)N * K / 8 + kThreads) / kThreads;
+            if (nb > 4096) nb = 4096;
+            hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, utok, (int64_t)N * K, u16);
+            if ((rc = check_launch("narrow_kernel"))) return rc;
+        }
+        if ((rc = launch_gemm_tn_bf16(dyr, Dm, Dm, u16, K, K, N, dW, K, stream))) return rc;
     }
     hipLaunchKernelGGL(iota_kernel, dim3(256), dim3(kThreads), 0, stream, iota, N);
     if (w16) {
@@ -2006,8 +2036,8 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         __bf16 *dy16 = (__bf16 *)(ws16 + U.dy16), *wt16 = (__bf16 *)(ws16 + U.wt16);
         size_t nb = ((size_t)N * Dm / 8 + kThreads) / kThreads;
         if (nb > 4096) nb = 4096;
-        if (dy16p) dy16 = const_cast<__bf16 *>(dy16p);
-        else hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dyp, (int64_t)N * Dm, dy16);
+        if (dy16p) dy16 = const_cast<__bf16 *>(dy16p);   // (else narrowed for dW above)
+        (void)nb;
         hipLaunchKernelGGL(transpose_bf16_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((Dm + 31) / 32)), dim3(kThreads), 0, stream,
                            (const __bf16 *)w16, Dm, K, wt16);
         if ((rc = check_launch("narrow/transpose"))) return rc;
