@@ -1776,20 +1776,29 @@ __global__ __launch_bounds__(kThreads) void narrow_kernel(const float *__restric
 // two reads make a lane's 8 contraction elements.  (Round 1 transposed dy and u in HBM first -- narrow_transpose /
 // transpose_bf16, 0.2 ms at 65 536 x 768 -- and contracted the token-minor copies: 0.30 ms more, with 85-fold split-k atomics.)
 // With 320-byte rows the four rows of a read sit 80 dwords apart: a 32-lane half (two groups, 32 columns) covers all 64 banks once.
-// Workgroup tile 128 x 128, 4 waves as 2 x 2, each 64 x 64; contraction split over blockIdx.z; partial tiles are added with
+// Workgroup tile 128 x 128, 2 x 4 waves as 2 x 2, each 64 x 64; contraction split over blockIdx.z; partial tiles are added with
 // float atomics (128-byte contiguous segments).  128 x 128 keeps the split count -- and with it the atomic volume
-// (splits x M x Kc x 4 bytes) -- at 7 for 768 x 768 on 256 CUs.
+// (splits x M x Kc x 4 bytes) -- at 8 for 768 x 768 (two workgroups per CU).
 typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
 typedef short s16x4w __attribute__((ext_vector_type(4)));
 constexpr int kTnRows = 64, kTnLd = 160;   // token rows per step; elements per staged row (128 data + 32 pad)
-__global__ __launch_bounds__(kThreads) void gemm_tn_bf16_kernel(const __bf16 *__restrict__ A_, int lda, int M, const __bf16 *__restrict__ B_, int ldb, int Kc,
-                                                                int64_t rows, int64_t rper, float *__restrict__ C, int ldc) {
+constexpr int kTnThreads = 512;            // 8 waves: two per SIMD.  Waves 0-3 and 4-7 are the same 2 x 2 grid of 64 x 64 sub-tiles and split the
+                                           // step's four 16-row contraction slices between them; the two partial tiles meet in LDS at the end
+__global__ __launch_bounds__(kTnThreads) void gemm_tn_bf16_kernel(const __bf16 *__restrict__ A_, int lda, int M, const __bf16 *__restrict__ B_, int ldb, int Kc,
+                                                                  int64_t rows, int64_t rper, int nz, float *__restrict__ C, int ldc) {
     extern __shared__ __attribute__((aligned(16))) __bf16 lds_tn[];   // [2][A | B][kTnRows][kTnLd]
     constexpr int kTile = kTnRows * kTnLd;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
-    const int m0 = blockIdx.x * 128, k0 = blockIdx.y * 128;
-    const int64_t r_lo = (int64_t)blockIdx.z * rper, r_hi = min(rows, r_lo + rper);
-    const int wm = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    // 1-D grid, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so ids 8 g .. 8 g + 7 take the SAME output tile and the
+    // contraction slices z = 0 .. 7: all tiles of one slice then run on one XCD and its rows of A and B come out of that XCD's L2
+    // (every row is wanted by gx + gy tiles; without this they were fetched once per XCD and tile: 1.2 GB instead of 0.2 at 65 536 x 768)
+    const int gx = (M + 127) / 128, tiles = gx * ((Kc + 127) / 128);
+    int tile, z;
+    if ((nz & 7) == 0) { const int g = blockIdx.x >> 3; tile = g % tiles; z = (blockIdx.x & 7) + 8 * (g / tiles); }
+    else { tile = blockIdx.x % tiles; z = blockIdx.x / tiles; }
+    const int m0 = (tile % gx) * 128, k0 = (tile / gx) * 128;
+    const int64_t r_lo = (int64_t)z * rper, r_hi = min(rows, r_lo + rper);
+    const int wm = ((wave >> 1) & 1) * 64, wk = (wave & 1) * 64, ws = wave >> 2;   // ws: which two of the four contraction slices
     f32x16b acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1797,12 +1806,12 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_bf16_kernel(const __bf16 *__
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    // staging: 64 rows x 16 pieces of 16 bytes per operand = 1024 pieces -> 4 per thread (16 lanes read one 256-byte row segment)
-    bf16x8w ra[4], rb[4];
+    // staging: 64 rows x 16 pieces of 16 bytes per operand = 1024 pieces -> 2 per thread (16 lanes read one 256-byte row segment)
+    bf16x8w ra[2], rb[2];
     auto load_stage = [&](int64_t r0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int q = p * kThreads + tid, row = q >> 4, c = (q & 15) * 8;
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kTnThreads + tid, row = q >> 4, c = (q & 15) * 8;
             ra[p] = (bf16x8w)((__bf16)0.f); rb[p] = (bf16x8w)((__bf16)0.f);
             if (r0 + row < r_hi) {   // M, Kc, lda, ldb are multiples of 8: a piece is wholly inside or outside
                 if (m0 + c < M) ra[p] = *(const bf16x8w *)(A_ + (r0 + row) * lda + m0 + c);
@@ -1813,8 +1822,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_bf16_kernel(const __bf16 *__
     auto store_stage = [&](int buf) {
         __bf16 *sA = lds_tn + buf * 2 * kTile, *sB = sA + kTile;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int q = p * kThreads + tid, row = q >> 4, c = (q & 15) * 8;
+        for (int p = 0; p < 2; ++p) {
+            const int q = p * kTnThreads + tid, row = q >> 4, c = (q & 15) * 8;
             *(bf16x8w *)(sA + row * kTnLd + c) = ra[p];
             *(bf16x8w *)(sB + row * kTnLd + c) = rb[p];
         }
@@ -1842,7 +1851,8 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_bf16_kernel(const __bf16 *__
         if (more) load_stage(r0 + kTnRows);
         const __bf16 *sA = lds_tn + buf * 2 * kTile, *sB = sA + kTile;
 #pragma unroll
-        for (int s16 = 0; s16 < kTnRows / 16; ++s16) {
+        for (int j = 0; j < 2; ++j) {
+            const int s16 = 2 * ws + j;
             bf16x8w af[2], bf[2];
 #pragma unroll
             for (int a = 0; a < 2; ++a) af[a] = frag(sA, s16, wm + 32 * a);
@@ -1856,6 +1866,18 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_bf16_kernel(const __bf16 *__
         if (more) store_stage(buf ^ 1);
         __syncthreads();
     }
+    // the second wave group's partial tile joins the first's through LDS (64 KB: the stage buffers are free now)
+    float *red = (float *)lds_tn + (size_t)(wave & 3) * 64 * 64;   // [a][b][r][lane] of one 64 x 64 sub-tile
+    if (ws == 1) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((a * 2 + b) * 16 + r) * 64 + lane] = acc[a][b][r];
+    }
+    __syncthreads();
+    if (ws == 1) return;
     // D[i][j]: lane -> j (B column = output column k), registers -> i (A column = output row m)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1864,23 +1886,27 @@ __global__ __launch_bounds__(kThreads) void gemm_tn_bf16_kernel(const __bf16 *__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h, k = k0 + wk + b * 32 + li;
-                if (m < M && k < Kc) atomicAdd(C + (int64_t)m * ldc + k, acc[a][b][r]);
+                if (m < M && k < Kc) atomicAdd(C + (int64_t)m * ldc + k, acc[a][b][r] + red[((a * 2 + b) * 16 + r) * 64 + lane]);
             }
 }
 
 // A, B: 16-byte aligned, lda / ldb / M / Kc multiples of 8
 static int launch_gemm_tn_bf16(const __bf16 *A_, int lda, int M, const __bf16 *B_, int ldb, int Kc, int64_t rows, float *C, int ldc, hipStream_t stream) {
     if (M <= 0 || Kc <= 0 || rows <= 0) return MOT_OK;
-    const int gx = (M + 127) / 128, gy = (Kc + 127) / 128;
-    int64_t splits = 256 / (gx * gy);   // one workgroup per CU; fewer splits = less atomic traffic
-    if (splits < 1) splits = 1;
+    const int tiles = ((M + 127) / 128) * ((Kc + 127) / 128);
+    // contraction slices: two workgroups per CU (80 KB of LDS each), a multiple of 8 for the XCD mapping, few enough to keep the
+    // atomic volume (slices x M x Kc x 4 bytes) small
+    int64_t splits = (512 / tiles) & ~7;
+    if (splits < 8) splits = 8;
+    if (splits > 32) splits = 32;
     int64_t rper = ((rows + splits - 1) / splits + kTnRows - 1) / kTnRows * kTnRows;
     if (rper < 4 * kTnRows) rper = 4 * kTnRows;
     splits = (rows + rper - 1) / rper;
+    if ((int64_t)tiles * splits > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_tn_bf16: too many tiles");
     const size_t lds = (size_t)4 * kTnRows * kTnLd * sizeof(__bf16);
     static std::atomic<uint64_t> lds_ok{0};
     if (int rc = ensure_max_dyn_lds((const void *)gemm_tn_bf16_kernel, lds_ok, "gemm_tn_bf16_kernel")) return rc;
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)splits), dim3(kThreads), lds, stream, A_, lda, M, B_, ldb, Kc, rows, rper,
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((unsigned)(tiles * splits)), dim3(kTnThreads), lds, stream, A_, lda, M, B_, ldb, Kc, rows, rper, (int)splits,
                        C, ldc);
     return check_launch("gemm_tn_bf16_kernel");
 }
