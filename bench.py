@@ -48,6 +48,7 @@ WORKLOADS = {
     # name: (B, T, vocab, bpt, d_model, byte_dim, byte_vocab, mode)
     "c4": (256, 2048, 50257, 16, 768, 48, 458, "sum"),     # headline: BASELINE configs[3]
     "c2": (64, 1024, 50257, 16, 768, 48, 458, "sum"),      # configs[1]
+    "c3": (128, 2048, 50257, 1, 768, 768, 100277, "dual"),  # configs[2]: GPT-2 + cl100k dual-BPE mix: a second TOKEN-level table, one id per position
     "c4big": (256, 2048, 128256, 16, 768, 48, 458, "sum"),  # the headline kernel over a 394 MB token table (> Infinity Cache)
     "c5": (256, 8192, 128256, 8, 2048, 2048, 132, "mean"),  # configs[4]: Llama-3 vocab, d 2048, 8 char slots, full batch
     "c5q": (64, 8192, 128256, 8, 2048, 2048, 132, "mean"),  # a quarter of it (round-1 record)
@@ -158,6 +159,10 @@ def make_inputs(wl, device, seed, uniform, rows=None, row0=0, vocab_override=Non
             bound = (3 ** 0.5) * 0.5 * K ** -0.5       # CastedLinear init, train_gpt.py:179-183
             weight = (torch.rand((D, K), generator=g, device=device, dtype=torch.float32) * 2 - 1) * bound
         return dict(toks=toks, tab=tab, tok_table=tok_table, byte_table=byte_table, ttb_kind=ttb_kind, weight=weight)
+    if mode == "dual":   # no counterpart in the reference: synthetic ids, both vocabularies FineWeb-shaped
+        toks = gi.fineweb_like_tokens(seed, row0 + rows, T, vocab=vocab, uniform=uniform)[row0:]
+        ids2 = gi.fineweb_like_tokens(seed + 7, row0 + rows, T, vocab=Vb, uniform=uniform)[row0:].astype(np.int64)
+        return dict(toks=toks, chars=ids2, tok_table=tok_table, byte_table=byte_table, ttb_kind="n/a (second id tensor given)")
     rs = np.random.RandomState(seed)
     toks = rs.randint(0, vocab, size=(row0 + rows, T)).astype(np.int32)[row0:]
     chars = rs.randint(0, Vb, size=(row0 + rows, T * bpt)).astype(np.int64)[row0:]
@@ -171,6 +176,8 @@ def algorithmic_bytes_per_token(wl, ids_mode, e=4):
         return 4 + 2 * bpt + e * WORKLOADS[wl][8] + e * D
     if mode == "sum":
         r = 4 + (2 * bpt if ids_mode == "fused" else 8 * bpt) + e * D
+    elif mode == "dual":
+        r = 4 + 8 + 2 * e * D          # two table rows per token
     else:
         r = 4 + 8 * bpt + e * D
     return r + e * D
@@ -211,6 +218,8 @@ def cpu_baseline(wl, inp, seconds):
             pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
             orc.embed_mix(toks, pulled, None, Et, Eb, mode="concat_linear", bpt=bpt, weight=inp["weight"].float().cpu().numpy(),
                           dtype=np.float32, norm_tok=True, norm_byte=True, norm_out=True)
+        elif mode == "dual":
+            orc.embed_mix(toks, inp["chars"][:rows], None, Et, Eb, mode="sum", bpt=1, dtype=np.float32, norm_out=True)
         else:
             orc.embed_mix(toks, inp["chars"][:rows], None, Et, Eb, mode="mean", bpt=bpt, dtype=np.float32)
 
@@ -358,6 +367,9 @@ def main(argv=None):
             from mixture_of_tokenizers_amd import data_creation as dc
             ids = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
             kwf = dict(mode="concat_linear", bpt=bpt, ids_a=ids, weight=inp["weight"], norm_tok=True, norm_byte=True, norm_out=True, out=out)
+    elif mode == "dual":
+        ids2 = torch.from_numpy(np.ascontiguousarray(inp["chars"])).to(device)
+        kwf = dict(mode="sum", bpt=1, ids_a=ids2, norm_out=True, out=out)
     else:
         chars = torch.from_numpy(np.ascontiguousarray(inp["chars"])).to(device)
         lt, lc = torch.tensor(1.0, device=device), torch.tensor(0.5, device=device)
