@@ -7,16 +7,17 @@
 // its time outside the contraction and runs the contraction itself at 23 % of the bf16 MFMA peak: 128 x 128 blocks read one
 // 16-byte LDS fragment per MFMA, and the concat operand makes two trips through HBM.  Here
 //   * a workgroup owns WHOLE output rows (64 MT tokens x all Dm = 128 NT columns; 8 waves as 2 x 4, a wave 32 MT x 32 NT), so
-//     the row norm is an epilogue (per-row sum of squares across the four column waves through LDS), and a fragment feeds
-//     MT or NT MFMAs;
+//     the row norm is an epilogue, and a fragment feeds MT or NT MFMAs;
 //   * the A operand is GATHERED: per 32-deep step a thread fetches one 16-byte piece of a token row or byte row, scales it by
 //     the row's rms factor, rounds to bf16 (the reference's rounding point: norm() returns a bf16 tensor) and writes it into the
 //     step's LDS tile -- the concat tensor never exists;
-//   * W is staged by LDS-DMA (global_load_lds, 16 bytes per lane, no staging registers), XOR-swizzled on the SOURCE side so that
-//     the lane-linear LDS image reads back without bank conflicts: piece p of row n sits at n * 64 + ((p ^ (n >> 2)) & 3) * 16;
-//   * the output tile leaves through LDS as whole 16-byte pieces (the composed kernel's 2-byte lane stores were a measurable part
-//     of its epilogue).
-// One barrier per step; the DMA of step s + 1 and the gathered pieces of step s + 1 are in flight while step s multiplies.
+//   * W is staged by LDS-DMA (global_load_lds, 16 bytes per lane, no staging registers) into NS stages, XOR-swizzled on the
+//     SOURCE side so that the lane-linear LDS image reads back without bank conflicts: piece p of row n sits at
+//     n * 64 + ((p ^ (n >> 2)) & 3) * 16;
+//   * the output tile leaves through LDS (the W stages, free by then) as whole 16-byte pieces: a lane holds NT consecutive outputs
+//     of a row (the stage rows of W are permuted for that), 32 lanes then take a row, sum its squares, scale and store.
+// Two barriers per step (the gathered tile is single-buffered: LDS is full); the DMA of steps s + 1 and s + 2 and the gathered
+// pieces of steps s + 1 and s + 2 are in flight while step s multiplies; every wait in the loop is counted (see the step).
 #include "mot_wave.hpp"
 #include <type_traits>
 // (clang wants the explicit captures below for operands of inline asm inside generic lambdas, and then calls them unused)
