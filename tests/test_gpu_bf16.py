@@ -324,6 +324,7 @@ def test_bf16_sum_backward_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
     (256, 48, 16, 1024, 2048, 2, 160, dict(norm_tok=True, norm_byte=True, norm_out=True, dual=True), 9803),
     (64, 16, 8, 128, 512, 1, 77, dict(norm_tok=True, norm_out=True), 9804),      # token count not a multiple of 8: the fp32-MFMA backward route
     (64, 16, 8, 128, 512, 3, 40, dict(norm_byte=True), 9805),                    # no post-norm: dy is the upstream gradient itself
+    (104, 24, 5, 384, 512, 2, 520, dict(norm_byte=True, norm_out=True, bytes_first=True), 9806),    # K = 224, Dm = 384: ragged dW tiles
 ])
 def test_bf16_concat_backward_through_autograd(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     kw = dict(kw)
