@@ -119,6 +119,12 @@ def test_bf16_limits(mot):
     (104, 24, 5, 384, 512, 2, 130, dict(norm_byte=True, norm_out=True, bytes_first=True), 9605),    # K = 224: ragged last K-step
     (64, 16, 8, 512, 700, 3, 171, dict(norm_tok=True, norm_out=True, bias=True), 9606),             # 513 tokens: a one-token last tile
     (128, 64, 2, 256, 300, 1, 1, dict(norm_byte=True), 9607),                                        # a single token
+    # corners of the gather-GEMM's piece walk (K a multiple of 32, dims multiples of 8, model_dim 256 / 512 / 1024)
+    (8, 8, 3, 256, 300, 2, 150, dict(norm_tok=True, norm_byte=True, norm_out=True), 9608),           # K = 32: ONE step (fewer than the two in flight)
+    (24, 40, 1, 256, 300, 2, 150, dict(norm_tok=True, norm_byte=True, norm_out=True), 9609),         # K = 64: a step straddles the two parts, byte_dim > 32
+    (56, 24, 7, 512, 300, 2, 150, dict(norm_byte=True, norm_out=True, bias=True), 9610),             # K = 224: byte slots straddle steps (24 does not divide 32)
+    (24, 8, 5, 512, 300, 2, 150, dict(norm_tok=True, norm_byte=True, bytes_first=True), 9611),       # K = 64, bytes first, four slots per step
+    (32, 16, 14, 1024, 300, 2, 150, dict(norm_tok=True, norm_byte=True, norm_out=True), 9612),       # K = 256, model_dim 1024: the 64-token tile, two slots per step
 ])
 @pytest.mark.parametrize("path", ["gather_gemm", "composed", "fused_tile"])
 def test_bf16_concat_linear_vs_oracle(mot, path, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
