@@ -172,11 +172,12 @@ def test_bf16_concat_linear_vs_oracle(mot, path, Dt, Db, bpt, Dm, Vt, B, T, kw, 
     assert (gotg == want).mean() > 0.97
 
 
+@pytest.mark.parametrize("B,T", [(3, 333), (9, 2003)], ids=["999_tokens", "18027_tokens"])   # 16 / 32 tokens per wave in the index pass
 @pytest.mark.parametrize("pull", ["left", "right", None])
-def test_bf16_gather_gemm_index_pass_outputs(mot, pull):
+def test_bf16_gather_gemm_index_pass_outputs(mot, pull, B, T):
     """The gather-GEMM path's own index pass (ids from the token->byte table, 16-bit in HBM): the int64 parity outputs and the pad
     statistics are the loader's (bit-exact vs the oracle), and the result equals the same call with those ids given."""
-    Dt, Db, bpt, Dm, Vt, B, T, seed = 128, 32, 16, 512, 3000, 3, 333, 9701    # 999 tokens: ragged units and a ragged last tile
+    Dt, Db, bpt, Dm, Vt, seed = 128, 32, 16, 512, 3000, 9701    # token counts: ragged units and a ragged last tile
     tab = gi.synth_ttb(seed + 1, Vt, bpt, pull or "left", mean_valid=4.4)
     toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.02)
     padded = orc.tokens_to_bytes(toks, tab.astype(np.float32))
