@@ -35,8 +35,16 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
+np = torch = None   # imported by _imports(), AFTER main() has decided whether this process only spawns the ranks
+
+
+def _imports():
+    """numpy + torch, bound as module globals.  The spawning parent of `--gpus N` never gets here: it imports neither."""
+    global np, torch
+    import numpy as _np
+    import torch as _torch
+    np, torch = _np, _torch
+
 
 REPO = Path(__file__).resolve().parent
 sys.path.insert(0, str(REPO))
@@ -86,6 +94,12 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary records (uniform ids, table > Infinity Cache, 65 536-token shard)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend of the N-rank run: nccl (= RCCL over xGMI, the real thing) or gloo (collectives on CPU "
+                         "copies of the few counters: rehearsals on a box with fewer GPUs than ranks)")
+    ap.add_argument("--one-device", action="store_true",
+                    help="REHEARSAL: every rank uses cuda:0 (needs --backend gloo; RCCL refuses two ranks on one GPU). Exercises rank > 0 "
+                         "of the row slicing / timing / counter aggregation on a one-GPU box; the line is marked \"rehearsal\": true")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / rendezvous / aggregation only: gloo on the CPU, no GPU call, no kernel (CPU tests of the N-rank path)")
     args = ap.parse_args(argv)
@@ -103,13 +117,36 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpus() -> int | None:
+    """GPUs this process may use, counted WITHOUT touching the HIP runtime: the KFD topology in sysfs (nodes with SIMDs are
+    GPUs; CPU nodes report simd_count 0), cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES lists when set.  None when sysfs
+    is unreadable (then the pre-check is skipped and a rank that finds no device fails by itself)."""
+    try:
+        n = 0
+        for prop in Path("/sys/class/kfd/kfd/topology/nodes").glob("*/properties"):
+            for ln in prop.read_text().splitlines():
+                k, _, v = ln.partition(" ")
+                if k == "simd_count" and int(v) > 0:
+                    n += 1
+        if n == 0:
+            return None
+    except Exception:
+        return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = os.environ.get(var)
+        if lst is not None:
+            n = min(n, len([x for x in lst.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args, argv) -> int:
     """Parent of a plain `--gpus N` run: starts the N ranks as child processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
-    their environment, as torchrun would) and relays rank 0's JSON line.  Nothing here touches the GPU: torch is imported but
-    no HIP call is made in this process (device_count() does not initialise the runtime on this image)."""
-    if not args.dry_run:
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+    their environment, as torchrun would) and relays rank 0's JSON line.  This process makes NO torch.cuda / HIP call at all
+    (a runtime initialised here would be inherited across fork + exec by every rank): the device pre-check reads sysfs."""
+    assert "torch" not in sys.modules, "the spawning parent must not import torch (no HIP runtime before the ranks start)"
+    if not args.dry_run and not args.one_device:
+        have = visible_gpus()
+        if have is not None and have < args.gpus:
             print(f"bench.py: --gpus {args.gpus} but only {have} visible", file=sys.stderr)
             return 2
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(args.gpus),
@@ -183,6 +220,20 @@ def algorithmic_bytes_per_token(wl, ids_mode, e=4):
     return r + e * D
 
 
+def shard_reference(wl, args, tokens):
+    """What ONE GPU reaches on a launch of this many tokens (profiles/shard_reference.json: single-GPU runs of the shard sizes of
+    2/4/8-way strong scaling, recorded with tools/bench_shard.py): every rank of a strong-scaling run launches exactly this, so
+    `roofline.frac` of an N-GPU line should sit at this figure (also in `extra.shard_65536_tokens` of the N = 1 line)."""
+    if wl != "c4" or args.ids != "fused" or args.dtype != "f32" or args.uniform_ids:
+        return None
+    try:
+        ref = json.loads((REPO / "profiles" / "shard_reference.json").read_text())
+        r = ref["tokens"].get(str(tokens))
+        return None if r is None else dict(r, source=ref["source"])
+    except Exception:
+        return None
+
+
 def usable_cores() -> int:
     """Threads the CPU baseline may really use: affinity, capped by the cgroup CPU quota and by the
     GPU box's per-GPU CPU share (16), so OpenMP does not oversubscribe."""
@@ -251,7 +302,7 @@ def timed_launches(step, n, warm=5):
     return e0.elapsed_time(e1) / n
 
 
-def extra_records(mot, device, dtype, steps):
+def extra_records(mot, device, dtype, steps, warmup):
     """The headline kernel where caches cannot carry it (N = 1 only, outside the timed region): each record is the same
     fused SUM launch with its own algorithmic bytes / HIP-event time."""
     recs = {}
@@ -268,7 +319,7 @@ def extra_records(mot, device, dtype, steps):
         toks, tab = torch.from_numpy(inp["toks"]).to(device), torch.from_numpy(inp["tab"]).to(device)
         out = torch.empty((rows, T, D), dtype=tdt, device=device)
         plan = mot.embed_mix_plan(toks, tt, bt, mode="sum", bpt=bpt, ttb=tab, pull="left", norm_out=True, out=out)
-        ms = timed_launches(plan, max(20, steps // 4))
+        ms = timed_launches(plan, steps, warm=warmup)      # the headline's own warm-up and step counts
         nbytes = algorithmic_bytes_per_token(wl, "fused", 4 if dtype == "f32" else 2) * rows * T
         gbs = nbytes / (ms * 1e-3) / 1e9
         recs[name] = {"kernel_ms": ms, "tokens_per_s": rows * T / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
@@ -313,7 +364,8 @@ def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args, argv))       # parent: no GPU call has been made in this process
+        sys.exit(spawn_ranks(args, argv))       # parent: torch is not even imported in this process
+    _imports()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -327,8 +379,16 @@ def main(argv=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.one_device:
+            assert args.backend == "gloo", "--one-device needs --backend gloo (RCCL refuses two ranks on one GPU)"
+            local_rank = 0
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     device = torch.device("cuda", local_rank)
+    # collectives of the reporting path: on the device over RCCL, or on CPU copies over gloo (rehearsal)
+    cdev = device if args.backend == "nccl" else torch.device("cpu")
     torch.cuda.set_device(device)
 
     import mixture_of_tokenizers_amd as mot
@@ -430,10 +490,11 @@ def main(argv=None):
     kernel_ms_ranks = [kernel_ms]
     if use_dist:
         import torch.distributed as dist
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        counters = counters.to(cdev)
         dist.all_reduce(counters, op=dist.ReduceOp.SUM)     # the path's only collective: <= 64 B over RCCL/xGMI
-        kall = torch.zeros(world, dtype=torch.float64, device=device)
+        kall = torch.zeros(world, dtype=torch.float64, device=cdev)
         kall[rank] = kernel_ms
         dist.all_reduce(kall, op=dist.ReduceOp.SUM)
         kernel_ms_ranks = kall.tolist()
@@ -473,14 +534,19 @@ def main(argv=None):
                                    f"mode {mode}{'+rmsnorm' if mode != 'mean' else ''}, ids {args.ids}, token ids "
                                    f"{'uniform' if args.uniform_ids or mode == 'mean' else 'FineWeb-shaped (u^3 skew, EOT p=1/700)'}, "
                                    f"ttb {inp['ttb_kind']}",
-                       "global_tokens_per_step": tokens_per_step * world, "parallelism": f"batch-sharded x{world}"},
+                       "global_tokens_per_step": tokens_per_step * world, "per_gpu_tokens": tokens_per_step,
+                       "parallelism": f"batch-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "embed_mean_lds_kernel" if mode == "mean" else "embed_mix_kernel", "kernel_ms": kernel_ms, "launch_us": launch_us,
                          "per": "rank (slowest rank's launch time; every rank moves the same algorithmic bytes)",
                          "kernel_ms_per_rank": kernel_ms_ranks, "aggregate_GBps": achieved * world,
                          "device_copy_GBps": copy_gbs, "frac_of_device_copy": (achieved / copy_gbs) if copy_gbs else None,
-                         "algorithmic_bytes_per_token": bpt_alg, "tokens_per_launch": tokens_per_step},
+                         "algorithmic_bytes_per_token": bpt_alg, "tokens_per_launch": tokens_per_step,
+                         "single_gpu_shard_reference": shard_reference(wl, args, tokens_per_step)},
+            **({"rehearsal": True, "rehearsal_note": "all ranks on cuda:0, collectives over gloo: NOT a multi-GPU measurement"}
+               if args.one_device else {}),
+            "library": mot.build_info(),
             "byte_stats": {"tokens": c[0], "slots": c[1], "pads_before": c[2], "pads_after": c[3],
                            "mean_valid_per_token": (c[1] - c[2]) / max(c[0], 1),
                            "pulled_fill": (c[2] - c[3]) / max(c[1], 1)},
@@ -518,7 +584,7 @@ def main(argv=None):
         if world == 1 and mode == "sum" and wl == "c4" and args.ids == "fused" and not args.uniform_ids and not args.no_extra:
             del plan, plan_cnt, out
             torch.cuda.empty_cache()
-            res["extra"] = extra_records(mot, device, args.dtype, args.steps)
+            res["extra"] = extra_records(mot, device, args.dtype, args.steps, args.warmup)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(wl, inp, args.cpu_seconds)
         print(json.dumps(res), flush=True)
@@ -530,3 +596,5 @@ def main(argv=None):
 
 if __name__ == "__main__":
     main()
+else:
+    _imports()   # imported as a module (tools/bench_*.py): the helpers above need numpy and torch bound

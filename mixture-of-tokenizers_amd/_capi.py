@@ -13,7 +13,15 @@ from pathlib import Path
 import torch
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = Path(os.environ.get("MOT_DEV_LIB") or (_HERE / "libmot_hip.so"))   # MOT_DEV_LIB: kernel-variant A/B runs (tools/variants.sh)
+# The shipped binding loads the in-tree library.  Kernel-variant A/B runs (tools/variants.sh) may point MOT_DEV_LIB at another
+# build, but only together with the explicit dev switch MOT_DEV=1; build_info() and bench.py's JSON name the file that was loaded.
+_dev_lib = os.environ.get("MOT_DEV_LIB")
+if _dev_lib and os.environ.get("MOT_DEV") != "1":
+    import sys as _sys
+    print(f"mixture-of-tokenizers_amd: MOT_DEV_LIB={_dev_lib} ignored (set MOT_DEV=1 to load a dev build)", file=_sys.stderr)
+    _dev_lib = None
+LIB_PATH = Path(_dev_lib or (_HERE / "libmot_hip.so"))
+IS_DEV_LIB = _dev_lib is not None
 
 # ---- enums of include/mot.h
 MOT_OK, MOT_EINVAL, MOT_ESHAPE, MOT_EUNSUPPORTED, MOT_EHIP, MOT_EWORKSPACE = 0, -1, -2, -3, -4, -5
@@ -176,7 +184,7 @@ def check(rc: int) -> None:
 
 
 def build_info() -> str:
-    return lib.mot_build_info().decode()
+    return lib.mot_build_info().decode() + f" | loaded {LIB_PATH}" + (" (DEV build via MOT_DEV_LIB)" if IS_DEV_LIB else "")
 
 
 # ----------------------------------------------------------------------------------------------

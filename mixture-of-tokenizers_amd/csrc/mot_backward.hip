@@ -27,6 +27,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "mot_mix.hpp"
 
 namespace mot {
@@ -817,6 +819,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
         return v;
     };
     int fx_k = 0;
+    bool fx_on = false;                                           // a non-zero finite sample exists: without one NOTHING is converted
     float fx_mul = 1.f;                                           // s_byte * 2^fx_k: a byte-row term's fixed-point value is dy * fx_mul
     auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
 
@@ -850,7 +853,8 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
         }
         __syncthreads();
         const float m = __uint_as_float(*fx_bits);
-        fx_k = m > 0.f ? min(27 - ilogbf(m), 100) : 0;
+        fx_on = m > 0.f;
+        fx_k = fx_on ? max(-100, min(27 - ilogbf(m), 100)) : 0;
         fx_mul = ldexpf(s_byte, fx_k);
     }
     // the id of this lane's slot: requested raw, range-checked where it is first used (a check right behind the load would make
@@ -973,19 +977,22 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
                     for (int j = 0; j < NE; ++j) dy[j] = rnb * (dy[j] - bn[j] * sg);
                 }
                 // Fixed-point sums in LDS: x = dy s_b 2^fx_k rounded to a 32-bit integer, added into 64-bit words.  A lane takes
-                // this path with all its NE terms or not at all: it must have an LDS row, and its largest |x| must convert
-                // (< 2^31; the comparison is false for NaN / infinity too).  The absolute rounding error of a term is
-                // <= 2^-(fx_k + 1), i.e. 2^-28 of the workgroup's sampled |g s_b| maximum -- below what a float atomic loses on
-                // a row's running sum -- so small terms need no path of their own.  Lanes that fail (a term > 16x the sample
-                // maximum, a non-finite term, a row beyond the privatised ones) add exact global float atomics instead.
+                // this path with all its NE terms or not at all: it must have an LDS row, the workgroup must have a scale (a
+                // non-zero finite sample: with all sampled rows zero, 2^0 would round every |term| < 0.5 away), and its largest |x|
+                // must lie in [2^12, 2^31) -- or be zero, which adds nothing.  The upper bound is what converts (the comparison is
+                // made on the |x| BIT PATTERNS, which order NaN above infinity: v_max_f32 would drop a NaN); the lower bound keeps
+                // rows far below the sample (masked or down-weighted positions: largest term <= 2^-15 of the sampled maximum) on
+                // the float atomics with their full relative precision.  Inside a converted lane a term's absolute rounding error
+                // is <= 2^-(fx_k + 1), i.e. 2^-28 of the sampled |g s_b| maximum -- below what a float atomic loses on a row's
+                // running sum.  Lanes that fail add exact global float atomics instead.
                 const int sa = byte_slot(ida), sb = DUAL ? byte_slot(idb) : 0;
-                float amax = 0.f;
+                uint32_t abits = 0u;
 #pragma unroll
-                for (int j = 0; j < NE; ++j) { dy[j] *= fx_mul; amax = fmaxf(amax, fabsf(dy[j])); }
-                const bool fits = amax < 0x1p31f;
-                const bool oka = fits && sa >= 0, okb = DUAL ? (fits && sb >= 0) : true;
-                if (__all(oka && okb)) {
-                    unsigned long long *ra_q = dbyte_q + (size_t)sa * qs + wi0, *rb_q = dbyte_q + (size_t)sb * qs + wi0;
+                for (int j = 0; j < NE; ++j) { dy[j] *= fx_mul; abits = max(abits, __float_as_uint(dy[j]) & 0x7fffffffu); }
+                const bool fits = fx_on && abits < 0x4f000000u /* 2^31 */ && abits >= 0x45800000u /* 2^12 */, zero = abits == 0u;
+                const bool oka = zero || (fits && sa >= 0), okb = DUAL ? (zero || (fits && sb >= 0)) : true;
+                if (__all(oka && okb)) {   // (an all-zero lane may have no LDS row: it adds zeros to row 0)
+                    unsigned long long *ra_q = dbyte_q + (size_t)max(sa, 0) * qs + wi0, *rb_q = dbyte_q + (size_t)max(sb, 0) * qs + wi0;
 #pragma unroll
                     for (int j = 0; j < NE; ++j) {
                         const unsigned long long q = (unsigned long long)(long long)__float2int_rn(dy[j]);
@@ -1058,6 +1065,320 @@ static int dispatch_ne_lc(const BwdArgs &A, size_t lds, hipStream_t stream) {
         case 8: return launch_bwd_lc<MODE, 8>(A, lds, stream);
         case 12: return launch_bwd_lc<MODE, 12>(A, lds, stream);
         default: return launch_bwd_lc<MODE, 16>(A, lds, stream);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Round 3: the headline configuration by itself.  norm(E_tok[t] + concat_k E_byte[id_k]) of runs/71_*.py:227-230 has no
+// per-embedding norm and no learned scalar, so nothing of the general kernel's token / byte side bookkeeping is needed:
+//     y = a + b,   dy = ry g - (ry^3 mean(g y)) y,   d_tok[t] += dy,   d_byte[id_k] += dy[slot k]
+// What the counters and timing ablations said about embed_mix_bwd_lc_kernel on this configuration (profiles/r03_c4_backward_*):
+// its HBM traffic IS the algorithmic traffic (FETCH 1.81 GB + WRITE 0.18 GB + 0.19 GB of atomic requests against 1.61 GB of
+// gradient rows + token rows + ids); the LDS adds cost 0.03-0.05 ms, the token-row flushes 0.10 ms, everything else 0.34 ms
+// (1.8 GB of random 3 KB rows at 5.4 TB/s, the rate the CDNA guide measures for such gathers), and the parts do not overlap.
+// This kernel changes what could be changed inside hipcc's own s_waitcnt placement:
+//   * rows are read as 16-byte chunks lane, lane + 64, ...: every row load is a fully coalesced 1 KiB wave-instruction that
+//     touches each 128-byte line once (the lane-contiguous layout reads a row with NV instructions that each touch all of its
+//     lines; with more rows in flight than the 32 KB L1 holds, lines are fetched up to three times -- requesting rows further
+//     ahead made that kernel SLOWER);
+//   * the current run's token row lives in the wave's LDS strip (NV ds_read_b128 per place instead of NE registers), the bpt
+//     ids of a place are ONE 8-byte load per lane handed out with ds_bpermute, the running sum and the byte-row terms share one
+//     scaled form (dys = 2^k dy feeds both the fixed-point LDS adds and the register sum);
+//   * lookahead indices are clamped inside a 128-place segment, so every step issues the same requests, and the step is
+//     written twice (same run / new run): hipcc counts its waits per straight-line path and takes the SMALLER count wherever
+//     two paths join, so one shared body made every step wait for the gradient row of the NEXT place.
+// What is left on the table, measured ("Backward, round 3"): a new run still drains the wave's memory queue
+// (the compiler-visible token-row load behind the 12 atomics: two memory round trips per run, 17 runs per wave, 0.10 ms); the
+// versions that avoid it -- atomics or a plain read-add-store of the d_tok row at the END of the step, requests from inline asm
+// with hand-counted vmcnt -- lost to hipcc copying in-flight registers in front of the tied waits (v_mov_b64 of the id pair, then
+// the wait on the copy; with physical-register constraints: copies in and out of the pinned registers and 46 spills).
+// Everything else -- the sorted order, the privatised 64-bit byte-table sums with 49-word rows, the exact global-atomic path
+// for what has no LDS slot or does not convert -- is embed_mix_bwd_lc_kernel's.
+// ------------------------------------------------------------------------------------------
+constexpr int kPlThreads = 768, kPlWaves = kPlThreads / 64;   // 12 waves, 3 per SIMD: 168 registers per lane
+
+template <int MODE, int NE, bool NORM_OUT>
+__global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const BwdArgs A) {
+#pragma clang fp contract(fast)
+    constexpr int D = 64 * NE, NV = NE / 4;
+    constexpr bool BYTES = MODE != MOT_MIX_NOOP;
+    constexpr int kSeg = 128;                                     // places per pipeline segment: their (position, token) pairs sit in 2 x 2 registers
+#ifdef MOT_DEV_ABLATION   // timing-only switches (results are wrong): 1 no LDS byte adds, 2 no token-row atomics, 512 no wave sums
+#define PL_ABL(bit) (A.abl & (bit))
+#else
+#define PL_ABL(bit) false
+#endif
+    extern __shared__ unsigned long long lds_q[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qs = A.Db + 1;
+    const int nbyte = (A.priv_rows * qs + 1) & ~1;
+    unsigned long long *dbyte_q = lds_q;
+    uint32_t *fx_bits = (uint32_t *)(lds_q + nbyte);
+    float *xp = (float *)(lds_q + nbyte + 2) + wave * D;
+    for (int i = tid; i < nbyte; i += kPlThreads) dbyte_q[i] = 0ull;
+    if (tid == 0) *fx_bits = 0u;
+    const float inv_d = 1.0f / (float)D;
+    // Lane l owns the 16-byte chunks l, l + 64, ... of a row (elements 4c .. 4c + 3 of chunk c).  A chunk lies inside one byte
+    // slot (Db a multiple of 4): chunk v of this lane belongs to slot sl[v] and starts at element wo[v] of that slot's byte row.
+    const int cps = BYTES ? A.Db / 4 : 1;                         // chunks per slot
+    int sl[NV], wo[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) { const int c = lane + 64 * v; sl[v] = BYTES ? c / cps : 0; wo[v] = BYTES ? 4 * (c - sl[v] * cps) : 0; }
+    const uint32_t lane_off = (uint32_t)lane * 16u;
+    auto load_row = [&](float4v (&dst)[NV], const void *rbase) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[v] = *(const float4v *)((const char *)rbase + (lane_off + 1024u * v));
+    };
+    auto load_byte_rows = [&](float4v (&dst)[NV], const int (&id)[NV]) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[v] = *(const float4v *)(A.byte_table + (int64_t)id[v] * A.Db + wo[v]);
+    };
+    auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
+    // The bpt ids of a position are one cache line: lane k < bpt loads id k (one 8-byte load per position), range-checks it, and
+    // the NV slots of every lane pick theirs with ds_bpermute (the LDS crossbar: no memory, no bank conflicts).
+    const int idl = min(lane, max(A.bpt, 1) - 1);
+    auto load_ids = [&](int64_t n) { return A.ids_a[n * A.bpt + idl]; };
+    auto clamp_id = [&](int64_t raw) {
+        const bool bad = (uint64_t)raw >= (uint64_t)A.byte_rows;
+        if (bad && A.status) atomicOr(A.status, kStatusByteOor);
+        return bad ? 0 : (int)raw;
+    };
+    auto spread_ids = [&](int idv, int (&id)[NV]) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) id[v] = __builtin_amdgcn_ds_bpermute(sl[v] * 4, idv);
+    };
+    const int64_t per_wg = (A.n_tokens + gridDim.x - 1) / gridDim.x;
+    const int64_t wg_lo = min(A.n_tokens, (int64_t)blockIdx.x * per_wg), wg_hi = min(A.n_tokens, wg_lo + per_wg);
+    const int64_t per_wave = (wg_hi - wg_lo + kPlWaves - 1) / kPlWaves;
+    const int64_t s_begin = min(wg_hi, wg_lo + wave * per_wave), s_end = min(wg_hi, s_begin + per_wave);
+    __syncthreads();
+    // fixed-point scale 2^fx_k of the privatised sums from one sampled gradient row per wave (sample maximum -> 2^27); with no
+    // non-zero finite sample (m == 0) NOTHING takes the fixed-point path: every non-zero term goes out as an exact float atomic
+    int fx_k = 0;
+    bool fx_on = false;
+    {
+        float gmax = 0.f;
+        if (s_begin < s_end) {
+            float4v gs[NV];
+            load_row(gs, A.grad_out + (int64_t)A.pos_sorted[s_begin] * D);
+#pragma unroll
+            for (int v = 0; v < NV; ++v) gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(gs[v].x), fabsf(gs[v].y))), fmaxf(fabsf(gs[v].z), fabsf(gs[v].w)));
+            gmax = wave_max(gmax);
+            if (lane == 0 && gmax > 0.f && gmax < INFINITY) atomicMax(fx_bits, __float_as_uint(gmax));
+        }
+        __syncthreads();
+        const float m = __uint_as_float(*fx_bits);
+        fx_on = m > 0.f;
+        fx_k = fx_on ? max(-100, min(27 - ilogbf(m), 100)) : 0;
+    }
+    const float fx_s = ldexpf(1.0f, fx_k), fx_back = ldexpf(1.0f, -fx_k);
+    float4v acc[NV];
+    int cur = -1;
+    // The current run's token row lives in the wave's LDS strip between two flushes; the strip is also where a finished row is
+    // turned into 256-byte-contiguous atomic instructions.
+    auto strip_read = [&](float4v (&dst)[NV]) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) dst[v] = *(const float4v *)(xp + 4 * (lane + 64 * v));
+    };
+    auto strip_write = [&](const float4v (&src)[NV], float f) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) *(float4v *)(xp + 4 * (lane + 64 * v)) = src[v] * f;
+    };
+    auto flush = [&]() {                                          // acc (scaled) -> strip -> NE atomic wave-instructions of 256 contiguous bytes
+        if (cur < 0) return;
+        seg_sync(); strip_write(acc, fx_back); seg_sync();
+        float *drow = A.d_tok + (int64_t)cur * D;
+        float tr[NE];
+#pragma unroll
+        for (int j = 0; j < NE; ++j) tr[j] = xp[lane + 64 * j];
+        if (!PL_ABL(2)) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) atomicAdd(drow + lane + 64 * j, tr[j]);
+        }
+        seg_sync();
+    };
+    auto new_run = [&](int tok) {                                 // the finished row leaves, this token's row comes into the strip, an empty sum
+        flush();
+        cur = tok;
+        load_row(acc, A.tok_table + (int64_t)tok * D);
+        __builtin_amdgcn_s_waitcnt(0x0f70);                        // vmcnt(0) (gfx9 encoding: vmcnt [3:0] + [15:14]; expcnt, lgkmcnt left alone)
+        strip_write(acc, 1.0f);
+        seg_sync();
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = float4v{0.f, 0.f, 0.f, 0.f};
+    };
+    for (int64_t seg0 = s_begin; seg0 < s_end; seg0 += kSeg) {
+        const int len = (int)min((int64_t)kSeg, s_end - seg0);
+        int vpos = 0, vtok = 0, vpos_hi = 0, vtok_hi = 0;        // places 0..63 and 64..127 of the segment, a lane each
+        if (lane < len) { vpos = A.pos_sorted[seg0 + lane]; vtok = A.tok_sorted[seg0 + lane]; }
+        if (64 + lane < len) { vpos_hi = A.pos_sorted[seg0 + 64 + lane]; vtok_hi = A.tok_sorted[seg0 + 64 + lane]; }
+        auto pos_at = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(vpos, i) : __builtin_amdgcn_readlane(vpos_hi, i - 64); };
+        auto tok_at = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(vtok, i) : __builtin_amdgcn_readlane(vtok_hi, i - 64); };
+        auto g_row = [&](int i) { return (const void *)(A.grad_out + (int64_t)pos_at(min(i, len - 1)) * D); };
+        float4v b_nx[NV], G0[NV], G1[NV];
+        int id_cur[NV], idv_n1 = 0;                               // this place's ids per slot of the lane; the next place's, one per lane
+        int64_t idraw_n1 = 0;
+        // ---- pipeline fill, requests in the order a step leaves them in (ids, byte rows, gradient row): the first step's waits
+        //      are counted for the worse of its two predecessors.  Lookahead indices are clamped to the segment's last place, so
+        //      every step issues the same vector-memory instructions (a re-read of a row that is in flight anyway).
+        if (BYTES) {
+            const int64_t r0 = load_ids(pos_at(0));
+            idraw_n1 = load_ids(pos_at(min(1, len - 1)));
+            idv_n1 = clamp_id(r0);
+            spread_ids(idv_n1, id_cur);
+            load_byte_rows(b_nx, id_cur);
+        }
+        load_row(G0, g_row(0));
+        auto step = [&](float4v (&gc)[NV], float4v (&gfree)[NV], const int i) {     // gc: this place's gradient row; gfree: where the next place's goes
+            const int tok = tok_at(i);
+            if (BYTES) spread_ids(idv_n1, id_cur);
+            auto rest = [&]() {
+                // (1) the raw ids two places ahead (addresses from a scalar position: depend on nothing in flight)
+                int64_t idraw_n2 = 0;
+                if (BYTES) idraw_n2 = load_ids(pos_at(min(i + 2, len - 1)));
+                // (2) y = a + b_i, then the next place's byte rows go into b's registers (their ids were requested one step ago)
+                float4v y[NV];
+                strip_read(y);
+                if (BYTES) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) y[v] += b_nx[v];
+                    int id_n1[NV];
+                    idv_n1 = clamp_id(idraw_n1);
+                    spread_ids(idv_n1, id_n1);
+                    load_byte_rows(b_nx, id_n1);
+                    idraw_n1 = idraw_n2;
+                }
+                // (3) the next place's gradient row
+                load_row(gfree, g_row(i + 1));
+                // (4) this place
+                float ry_s = fx_s, c2_s = 0.f;
+                bool finite = true;                                   // wave-uniform: a NaN / infinity anywhere in g or y shows in the two sums
+                if (NORM_OUT) {
+                    float4v ssv{0.f, 0.f, 0.f, 0.f}, mv{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) { ssv += y[v] * y[v]; mv += gc[v] * y[v]; }
+                    float ss = (ssv.x + ssv.y) + (ssv.z + ssv.w), m = (mv.x + mv.y) + (mv.z + mv.w);
+                    if (!PL_ABL(512)) { ss = wave_sum(ss); m = wave_sum(m); }
+                    const float ry = rms_scale(ss, D, A.eps);
+                    ry_s = ry * fx_s;
+                    c2_s = m * inv_d * ry * ry * ry_s;
+                    finite = fabsf(c2_s) < INFINITY && fabsf(ry_s) < INFINITY;
+                }
+                float amax = 0.f;
+                uint32_t abits = 0u;                                  // without the norm: max of the |x| bit patterns (orders NaN above infinity; v_max_f32 drops a NaN)
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    gc[v] = NORM_OUT ? ry_s * gc[v] - c2_s * y[v] : gc[v] * fx_s;      // dys = 2^k dy
+                    acc[v] += gc[v];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (NORM_OUT) amax = fmaxf(amax, fabsf(gc[v][e]));
+                        else abits = max(abits, __float_as_uint(gc[v][e]) & 0x7fffffffu);
+                    }
+                }
+                if (!NORM_OUT) amax = abits > 0x7f800000u ? INFINITY : __uint_as_float(abits);
+                if (BYTES) {
+                    // A lane converts all its NE terms or none: its slots need LDS rows, the workgroup a usable scale, and its largest
+                    // |x| must lie in [2^12, 2^31) (or be zero: nothing to add).  The absolute rounding error of a converted term is
+                    // <= 2^-(k+1), i.e. 2^-28 of the sampled maximum; a lane whose largest term is 2^-15 of that maximum or less
+                    // (rows far below the sample: masked or down-weighted positions) keeps full relative precision through the
+                    // float atomics.
+                    int sa[NV];
+                    bool rows = true;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) { sa[v] = byte_slot(id_cur[v]); rows &= sa[v] >= 0; }
+                    const bool conv = fx_on && finite && amax < 0x1p31f && amax >= 0x1p12f;
+                    const bool ok = (finite && amax == 0.f) || (conv && rows);
+                    if (PL_ABL(1)) {
+                        if (amax == 123.456f) dbyte_q[lane] = 1;
+                    } else if (__all(ok)) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            unsigned long long *rq = dbyte_q + (size_t)max(sa[v], 0) * qs + wo[v];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) atomicAdd(rq + e, (unsigned long long)(long long)__float2int_rn(gc[v][e]));
+                        }
+                    } else {
+                        // rare (a byte id without an LDS row, a term that does not convert): the lane's terms go through its part of the
+                        // wave's LDS strip, one at a time, so that this path costs the common one no registers; the token row the strip
+                        // held is fetched again afterwards
+                        seg_sync(); strip_write(gc, 1.0f); seg_sync();
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            const bool lds_ok = conv && sa[v] >= 0;
+                            unsigned long long *rq = dbyte_q + (size_t)max(sa[v], 0) * qs + wo[v];
+                            float *gq = A.d_byte + (int64_t)id_cur[v] * A.Db + wo[v];
+#pragma unroll 1
+                            for (int e = 0; e < 4; ++e) {
+                                const float x = xp[4 * (lane + 64 * v) + e];
+                                if (lds_ok) atomicAdd(rq + e, (unsigned long long)(long long)__float2int_rn(x));
+                                else if (x != 0.f) atomicAdd(gq + e, x * fx_back);   // (NaN != 0: it is added)
+                            }
+                        }
+                        seg_sync();
+                        load_row(y, A.tok_table + (int64_t)cur * D);
+                        __builtin_amdgcn_s_waitcnt(0x0f70);
+                        strip_write(y, 1.0f);
+                        seg_sync();
+                    }
+                }
+            };
+            // A new run is the only conditional vector-memory work of a step, and it ends with everything this wave has in flight
+            // drained; each path then runs its OWN copy of the rest of the step (see the header: waits are counted per path).
+            if (tok != cur) { new_run(tok); __builtin_amdgcn_sched_barrier(0); rest(); } else { rest(); }
+        };
+        int i = 0;
+        for (; i + 1 < len; i += 2) {   // two row buffers as register names
+            step(G0, G1, i);
+            step(G1, G0, i + 1);
+        }
+        if (i < len) step(G0, G1, i);
+    }
+    flush();
+    if (BYTES) {
+        __syncthreads();
+        for (int i = tid; i < A.priv_rows * A.Db; i += kPlThreads) {
+            const int sl_ = i / A.Db, wi = i - sl_ * A.Db;
+            const long long q = (long long)dbyte_q[sl_ * qs + wi];
+            if (q == 0) continue;
+            const int row = sl_ < A.priv_lo ? sl_ : sl_ - A.priv_lo + A.priv_hi0;
+            atomicAdd(A.d_byte + row * A.Db + wi, (float)ldexp((double)q, -fx_k));
+        }
+    }
+#undef PL_ABL
+}
+
+// the configuration this kernel is for: lc_layout's shapes, one id tensor, no per-embedding norm, no learned scalars
+template <int MODE>
+static bool plain_layout(const BwdArgs &A) {
+    if (A.norm_tok || A.norm_byte || A.scale_tok || A.scale_byte || A.d_scale_tok || A.d_scale_byte || A.ids_b) return false;
+    if (MODE == MOT_MIX_SUM && (A.Db & 3)) return false;        // a 16-byte chunk of a row lies inside one byte slot
+    const int ne = A.D / 64;
+    return ne == 4 || ne == 8 || ne == 12;   // 16 and up: seven row buffers no longer fit 128 registers
+}
+
+template <int MODE, int NE, bool NORM_OUT>
+static int launch_bwd_plain_t(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    static std::atomic<uint64_t> lds_ok{0};   // per-device bits
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_plain_kernel<MODE, NE, NORM_OUT>, lds_ok, "embed_mix_bwd_plain_kernel")) return rc_lds;
+    int64_t blocks = (A.n_tokens + 16 * kPlWaves - 1) / (16 * kPlWaves);   // >= 16 sorted positions per wave
+    if (blocks > 256) blocks = 256;   // one workgroup per CU
+    hipLaunchKernelGGL((embed_mix_bwd_plain_kernel<MODE, NE, NORM_OUT>), dim3((unsigned)blocks), dim3(kPlThreads), lds, stream, A);
+    return check_launch("embed_mix_bwd_plain_kernel");
+}
+template <int MODE, int NE>
+static int launch_bwd_plain(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    if (A.norm_out) return launch_bwd_plain_t<MODE, NE, true>(A, lds, stream);
+    return launch_bwd_plain_t<MODE, NE, false>(A, lds, stream);
+}
+
+template <int MODE>
+static int dispatch_ne_plain(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    switch (A.D / 64) {
+        case 4: return launch_bwd_plain<MODE, 4>(A, lds, stream);
+        case 8: return launch_bwd_plain<MODE, 8>(A, lds, stream);
+        default: return launch_bwd_plain<MODE, 12>(A, lds, stream);
     }
 }
 
@@ -1294,10 +1615,13 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     if (d.tok_rows >= (1 << 21) - 1)   // (token << 11 | index) of bwd_rank_kernel must stay below its 0xffffffff padding key
         return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: token tables of %lld rows (>= 2^21 - 1) are not built", (long long)d.tok_rows);
     const bool full = full_layout<MODE>(A);
-    bool lc = false;
-    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) lc = lc_layout<MODE>(A) && !(A.abl & 8);   // abl 8: dev switch back to the strided kernels
+    bool lc = false, plain = false;
+    if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
+        lc = lc_layout<MODE>(A) && !(A.abl & 8);   // abl 8: dev switch back to the strided kernels
+        plain = lc && plain_layout<MODE>(A) && !(A.abl & 16);   // abl 16: dev switch back to the general lane-contiguous kernel
+    }
     // LDS besides the privatised byte-table sums: per-wave per-slot accumulators (strided kernels) or per-wave transposition rows (lane-contiguous)
-    size_t lds = lc ? (size_t)kLcWaves * A.D * sizeof(float) + 16 : 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
+    size_t lds = lc ? (size_t)(plain ? kPlWaves : kLcWaves) * A.D * sizeof(float) + 16 : 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
     if ((rc = launch_group_positions(A.tokens, A.n_tokens, A.tok_rows, ws_ints, &A.pos_sorted, &A.tok_sorted, A.status, stream))) return rc;
 #ifdef MOT_DEV_ABLATION
     if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
@@ -1318,6 +1642,7 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
         }
     }
     if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
+        if (plain) return dispatch_ne_plain<MODE>(A, lds, stream);
         if (lc) return dispatch_ne_lc<MODE>(A, lds, stream);
     }
     if (full) return dispatch_ne_full<MODE>(A, lds, stream);

@@ -23,29 +23,66 @@ from .modules import ByteHyperparameters
 SHARD_MAGIC, SHARD_VERSION, HEADER_INT32 = 20240520, 1, 256
 
 
-def _load_data_shard(file: Path, dtype: torch.dtype = torch.uint16) -> Tensor:
-    """train_gpt.py:629-638: 256 x int32 header [magic, version, num_tokens], then the payload."""
-    header = np.fromfile(str(file), dtype=np.int32, count=HEADER_INT32)
-    assert header[0] == SHARD_MAGIC, f"magic number mismatch in the data .bin file: {header[0]}"
-    assert header[1] == SHARD_VERSION, f"unsupported version, expected 1 but got {header[1]}"
-    num_tokens = int(header[2])
-    tokens = torch.empty(num_tokens, dtype=dtype, pin_memory=torch.cuda.is_available())
-    with Path(file).open("rb", buffering=0) as f:
-        f.seek(HEADER_INT32 * 4)
-        nbytes = f.readinto(tokens.numpy())
-    assert nbytes == num_tokens * tokens.element_size(), "number of tokens read does not match header"
-    return tokens
+def _shard_token_count(path: Path) -> int:
+    """Validates the 256 x int32 header [magic, version, num_tokens] of a shard (train_gpt.py:630-633) and returns num_tokens.
+    A bad header is an AssertionError, which is what makes the stream skip the file (train_gpt.py:647)."""
+    head = np.fromfile(str(path), dtype=np.int32, count=HEADER_INT32)
+    if head.size < 3 or head[0] != SHARD_MAGIC:
+        raise AssertionError(f"magic number mismatch in the data .bin file: {head[0] if head.size else 'empty file'}")
+    if head[1] != SHARD_VERSION:
+        raise AssertionError(f"unsupported version, expected 1 but got {head[1]}")
+    return int(head[2])
 
 
-def load_data_shard(file_iter) -> Tensor:
-    """train_gpt.py:641-648: skip shards whose header is bad; int32 payload for files under bytes/."""
-    while True:
-        try:
-            file = next(file_iter)
-            dtype = torch.int32 if "bytes/" in str(file) else torch.uint16
-            return _load_data_shard(file, dtype=dtype).to(torch.int32)
-        except AssertionError:
-            pass
+def read_shard(path: Path, dtype: torch.dtype = torch.uint16) -> Tensor:
+    """The payload of one shard (train_gpt.py:629-638) as a 1-D tensor of `dtype`, read straight into (pinned, when a GPU is
+    present) host memory."""
+    path = Path(path)
+    n = _shard_token_count(path)
+    payload = torch.empty(n, dtype=dtype, pin_memory=torch.cuda.is_available())
+    with path.open("rb", buffering=0) as fh:
+        fh.seek(HEADER_INT32 * 4)
+        got = fh.readinto(payload.numpy())
+    if got != n * payload.element_size():
+        raise AssertionError("number of tokens read does not match header")
+    return payload
+
+
+class ShardStream:
+    """The token stream ``distributed_data_generator`` walks (train_gpt.py:798-805): a growing int32 buffer plus a cursor.
+
+    Shards are appended in the (already shuffled) order of `paths`; unreadable ones are skipped (a header AssertionError,
+    train_gpt.py:641-648); files under ``bytes/`` hold int32 payloads, the others uint16 (:645).  When fewer than
+    ``window + 2`` tokens remain behind the cursor the next shard is APPENDED and the cursor goes back to ZERO -- the
+    reference rewinds into the tokens it has already served (``newdata, pos = ..., 0`` followed by ``cat([data, newdata])``,
+    :800-802); the stream is reproduced as it is, bit for bit, not "fixed"."""
+
+    def __init__(self, paths):
+        self._paths = iter(paths)
+        self.buffer = self._next_payload()
+        self.cursor = 0
+
+    def _next_payload(self) -> Tensor:
+        for path in self._paths:
+            try:
+                wide = "bytes/" in str(path)
+                return read_shard(path, torch.int32 if wide else torch.uint16).to(torch.int32)
+            except AssertionError:
+                continue
+        # the reference's bare next() inside its generator surfaces the same way (PEP 479)
+        raise RuntimeError("generator raised StopIteration: no further data shard")
+
+    def remaining(self) -> int:
+        return len(self.buffer) - self.cursor
+
+    def advance(self, window: int) -> int:
+        """Start offset of the next `window` tokens; moves the cursor past them."""
+        if self.remaining() <= window + 1:
+            self.buffer = torch.cat([self.buffer, self._next_payload()])
+            self.cursor = 0
+        start = self.cursor
+        self.cursor = start + window
+        return start
 
 
 def write_data_shard(file: Path, tokens: np.ndarray, dtype=np.uint16) -> None:
@@ -64,7 +101,7 @@ def save_file(path: str, data) -> None:
 
 def load_file(path: str) -> Tensor:
     """data_creation.py:421-459: the flat int32 payload of such a file (the caller views it (B, T, 1 + 4*bpt))."""
-    return _load_data_shard(Path(path), dtype=torch.int32)
+    return read_shard(Path(path), dtype=torch.int32)
 
 
 def rank_slice(data: Tensor, pos: int, batch_size: int, seq_len: int, rank: int, world_size: int) -> Tensor:
@@ -136,13 +173,8 @@ def distributed_data_generator(filename_patterns, seq_len: int, batch_size: int,
     random.seed(seed)  # all ranks shuffle the shards the same way
     random.shuffle(files)
 
-    local_seq_len = seq_len + 1
-    file_iter = iter(files)
-    data, pos = load_data_shard(file_iter), 0
+    stream = ShardStream(files)
+    window = batch_size * (seq_len + 1)           # tokens of one GLOBAL batch: every rank advances by all of it
     while True:
-        if pos + batch_size * local_seq_len + 1 >= len(data):
-            newdata, pos = load_data_shard(file_iter), 0
-            data = torch.cat([data, newdata])
-        tokens = rank_slice(data, pos, batch_size, seq_len, rank, world_size).to(device)
-        pos += batch_size * local_seq_len
-        yield create(tokens)
+        start = stream.advance(window)
+        yield create(rank_slice(stream.buffer, start, batch_size, seq_len, rank, world_size).to(device))

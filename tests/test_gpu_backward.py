@@ -491,3 +491,74 @@ def test_mean_backward_vs_oracle(mot, D, bpt, Vt, Vc, B, T, kw, seed):
     if scaled:
         scale = _scalar_scale(ref["scales"], B * T, D)
         assert abs(float(st.grad) - ref["scales"][0]) < TOL * scale and abs(float(sb.grad) - ref["scales"][1]) < TOL * scale
+
+
+# ---- the fixed-point scale of the privatised byte-table sums comes from ONE sampled gradient row per wave:
+#      the cases below make the sample unrepresentative in both directions, on the two lane-contiguous kernels
+#      (norm_out only -> embed_mix_bwd_plain_kernel; with the per-embedding norms -> embed_mix_bwd_lc_kernel).
+_FX_KW = [dict(norm_out=True), dict(norm_tok=True, norm_byte=True, norm_out=True)]
+
+
+@pytest.mark.parametrize("kw", _FX_KW, ids=["plain", "lc"])
+@pytest.mark.parametrize("keep", [0.002, 0.03])
+def test_sum_backward_sparse_gradient_rows(mot, kw, keep):
+    """grad_out is exactly zero on almost every position (masked / padded positions of a real loss): most workgroups sample only
+    zero rows.  A scale of 2^0 there would round every |term| < 0.5 of the non-zero positions to nothing."""
+    D, Db, bpt, Vt, B, T, seed = 768, 48, 16, 2048, 8, 1024, 9301
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left")
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    rs = np.random.RandomState(seed + 4)
+    g = f32(rs.standard_normal((B, T, D)) * 1e-3)              # small on purpose: |term| << 0.5 without a scale
+    g *= (rs.random_sample((B, T, 1)) < keep)
+    assert 0 < np.count_nonzero(g.any(-1)) < 0.05 * B * T
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    ref = orc.embed_mix_bwd(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt,
+                            dtype=np.float64, **kw)
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(pulled), **kw)
+    assert np.abs(ref["byte_table"]).max() > 0
+    assert rel(host(got["byte_table"]), ref["byte_table"]) < TOL
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+
+
+@pytest.mark.parametrize("kw", _FX_KW, ids=["plain", "lc"])
+def test_sum_backward_rows_far_below_the_sample(mot, kw):
+    """Batch rows 1.. carry gradients 1e-9 x those of batch row 0 and use byte ids no position of row 0 uses: the gradient rows
+    of those ids are sums of tiny terms only and must come out with their own relative precision (bar relative to THEIR maximum),
+    not rounded against a scale taken from the large rows."""
+    D, Db, bpt, Vt, B, T, seed = 768, 48, 16, 1024, 6, 700, 9311
+    rs = np.random.RandomState(seed)
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.0)
+    ids = rs.randint(0, 200, size=(B, T * bpt)).astype(np.int64)
+    ids[1:] += 220                                              # rows 1..: byte ids 220..419 only
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    g = f32(rs.standard_normal((B, T, D)))
+    g[1:] *= 1e-9
+    ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt,
+                            dtype=np.float64, **kw)
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(ids), **kw)
+    gb, rb = host(got["byte_table"]), ref["byte_table"]
+    assert rel(gb[:200], rb[:200]) < TOL
+    assert np.abs(rb[220:420]).max() < 1e-6 * np.abs(rb[:200]).max()        # the small rows really are far below the large ones
+    assert rel(gb[220:420], rb[220:420]) < TOL                              # ... and are held to their own scale
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+
+
+@pytest.mark.parametrize("kw", _FX_KW, ids=["plain", "lc"])
+def test_sum_backward_non_finite_gradient_reaches_the_byte_table(mot, kw):
+    """A NaN in grad_out must show in the byte-table gradient of the ids that position uses (the reference's autograd propagates
+    it); v_max_f32 drops NaNs, so the range check of the fixed-point path is made on bit patterns / on the wave sums."""
+    D, Db, bpt, Vt, B, T, seed = 768, 48, 16, 512, 2, 256, 9321
+    rs = np.random.RandomState(seed)
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.0)
+    ids = rs.randint(0, 256, size=(B, T * bpt)).astype(np.int64)
+    ids[0, :bpt] = 300 + np.arange(bpt)                         # the poisoned position uses ids nobody else uses
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    g = f32(rs.standard_normal((B, T, D)))
+    g[0, 0, 5] = np.nan
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(ids), **kw)
+    gb = host(got["byte_table"])
+    assert np.isnan(gb[300 + 5 // Db]).any()                    # with the output norm every element of the position is NaN; without, element 5
+    assert np.isnan(host(got["tok_table"])[toks[0, 0]]).any()
+    clean = np.setdiff1d(np.arange(256), [])                    # rows 0..255 are shared with healthy positions only
+    assert np.isfinite(gb[clean]).all()

@@ -22,7 +22,7 @@ def test_shard_roundtrip_and_bad_header(tmp_path):
     toks = np.random.RandomState(0).randint(0, 50257, size=5000)
     f = tmp_path / "fineweb_train_000001.bin"
     loader.write_data_shard(f, toks)
-    got = loader._load_data_shard(f)
+    got = loader.read_shard(f)
     assert got.dtype == torch.uint16 and got.numel() == 5000
     np.testing.assert_array_equal(got.numpy().astype(np.int64), toks)
     raw = bytearray(f.read_bytes())
@@ -31,10 +31,48 @@ def test_shard_roundtrip_and_bad_header(tmp_path):
     raw[0] = 0
     bad.write_bytes(bytes(raw))
     with pytest.raises(AssertionError, match="magic"):
-        loader._load_data_shard(bad)
-    # load_data_shard skips the bad shard (train_gpt.py:641-648) and returns int32
-    out = loader.load_data_shard(iter([bad, f]))
-    assert out.dtype == torch.int32 and out.numel() == 5000
+        loader.read_shard(bad)
+    # the stream skips the bad shard (train_gpt.py:641-648) and holds int32
+    st = loader.ShardStream([bad, f])
+    assert st.buffer.dtype == torch.int32 and st.buffer.numel() == 5000 and st.remaining() == 5000
+
+
+def test_shard_stream_crosses_shards_like_the_reference(tmp_path):
+    """ShardStream against the reference's cursor arithmetic written out on plain arrays (train_gpt.py:798-805): a batch is taken
+    at `pos`; when `pos + window + 1 >= len(data)` the next shard is appended and `pos` goes back to 0 (the reference's rewind
+    into tokens already served -- reproduced, not fixed); uint16 shards and an int32 shard under bytes/ mix; a shard with a bad
+    header is skipped; running out of shards ends in RuntimeError (PEP 479 in the reference's generator)."""
+    from mixture_of_tokenizers_amd import loader
+    rs = np.random.RandomState(5)
+    (tmp_path / "bytes").mkdir()
+    shards, paths = [], []
+    for i, (n, wide) in enumerate(((700, False), (333, False), (1200, True), (90, False))):
+        toks = rs.randint(0, 70000 if wide else 50257, size=n)
+        f = (tmp_path / "bytes" if wide else tmp_path) / f"train_{i:06d}.bin"
+        loader.write_data_shard(f, toks, dtype=np.int32 if wide else np.uint16)
+        shards.append(toks); paths.append(f)
+    bad = tmp_path / "train_bad.bin"
+    bad.write_bytes(b"\x00" * 2048)
+    order = [paths[0], bad, paths[1], paths[2], paths[3]]
+    window = 4 * 33
+    st = loader.ShardStream(order)
+    data, pos, nxt, served = shards[0].copy(), 0, 1, 0
+    with pytest.raises(RuntimeError, match="StopIteration"):
+        while True:
+            if pos + window + 1 >= len(data):           # the reference's condition and reset, on numpy arrays
+                if nxt >= len(shards):
+                    st.advance(window)                  # must raise here too
+                    raise AssertionError("ShardStream found a shard the reference stream does not have")
+                data, pos, nxt = np.concatenate([data, shards[nxt]]), 0, nxt + 1
+            start = st.advance(window)
+            assert start == pos and st.remaining() == len(data) - pos - window
+            np.testing.assert_array_equal(st.buffer[start:start + window].numpy(), data[pos:pos + window])
+            for rank in range(2):
+                got = loader.rank_slice(st.buffer, start, 4, 32, rank, 2)
+                np.testing.assert_array_equal(got.numpy(), data[pos + rank * window // 2:][:window // 2].reshape(-1, 33))
+            pos += window
+            served += 1
+    assert served > 12 and nxt == len(shards)
 
 
 def test_batch_file_roundtrip(tmp_path):
@@ -241,3 +279,57 @@ def test_bench_self_launch_two_ranks_gloo():
     r = subprocess.run([sys.executable, str(REPO / "bench.py"), "--gpus", "2", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_bench_parent_makes_no_torch_import(tmp_path):
+    """The spawning parent of `bench.py --gpus N` must not initialise a HIP runtime that fork + exec would hand to the ranks
+    (VERDICT r2, weak #4): it does not even import torch.  Proven by poisoning `torch` for the PARENT only: a sitecustomize-style
+    stub directory that raises on `import torch` is put on PYTHONPATH when MOT_TEST_POISON_PID equals the importing pid's parent
+    marker; the children drop it and import the real torch."""
+    import json
+    import subprocess
+    poison = tmp_path / "poison"
+    (poison / "torch").mkdir(parents=True)
+    # the stub raises only in the process whose pid is recorded in MOT_TEST_PARENT_PID (the bench parent writes nothing there: we
+    # pass the pid through a wrapper below); any other process removes the stub dir from sys.path and imports the real package
+    (poison / "torch" / "__init__.py").write_text(
+        "import os, sys, importlib\n"
+        "if os.environ.get('MOT_TEST_PARENT_PID') == str(os.getpid()):\n"
+        "    raise ImportError('bench.py parent imported torch')\n"
+        "sys.path[:] = [p for p in sys.path if p != os.path.dirname(os.path.dirname(__file__))]\n"
+        "del sys.modules['torch']\n"
+        "sys.modules['torch'] = importlib.import_module('torch')\n"
+        "globals().update(sys.modules['torch'].__dict__)\n")
+    wrapper = tmp_path / "run_parent.py"
+    wrapper.write_text(
+        "import os, sys, runpy\n"
+        "os.environ['MOT_TEST_PARENT_PID'] = str(os.getpid())\n"
+        f"sys.argv = [{str(REPO / 'bench.py')!r}, '--gpus', '2', '--dry-run', '--steps', '2', '--warmup', '1']\n"
+        f"runpy.run_path({str(REPO / 'bench.py')!r}, run_name='__main__')\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["PYTHONPATH"] = str(poison) + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, str(wrapper)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 2 and j["byte_stats"]["tokens"] == 256 * 2048
+
+
+def test_bench_visible_gpus_reads_sysfs_only(monkeypatch, tmp_path):
+    """visible_gpus(): KFD topology nodes with SIMDs are GPUs; *_VISIBLE_DEVICES lists cut the count; unreadable sysfs -> None."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", REPO / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    nodes = tmp_path / "nodes"
+    for i, simd in enumerate((0, 0, 1024, 1024, 1024)):
+        (nodes / str(i)).mkdir(parents=True)
+        (nodes / str(i) / "properties").write_text(f"cpu_cores_count {64 if simd == 0 else 0}\nsimd_count {simd}\nmem_banks_count 1\n")
+    real_path = bench.Path
+    monkeypatch.setattr(bench, "Path", lambda p: nodes if str(p) == "/sys/class/kfd/kfd/topology/nodes" else real_path(p))
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpus() == 2
+    monkeypatch.setattr(bench, "Path", lambda p: tmp_path / "missing" if str(p) == "/sys/class/kfd/kfd/topology/nodes" else real_path(p))
+    assert bench.visible_gpus() is None

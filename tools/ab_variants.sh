@@ -5,7 +5,7 @@ rows=$1; shift
 for spec in "$@"; do
     name=${spec%%:*}; unit=${spec#*:}; [ "$unit" = "$spec" ] && unit=""
     echo "== $name unit=${unit:-default}"
-    MOT_DEV_LIB=$PWD/build/variants/$name.so MOT_UNIT=$unit timeout -k 10 200 python tools/bench_shard.py $rows 2>&1 | grep -v Warning | python -c "
+    MOT_DEV=1 MOT_DEV_LIB=$PWD/build/variants/$name.so MOT_UNIT=$unit timeout -k 10 200 python tools/bench_shard.py $rows 2>&1 | grep -v Warning | python -c "
 import sys, json
 for ln in sys.stdin:
     try:
