@@ -175,6 +175,9 @@ def make_inputs(wl, device, seed, uniform, rows=None, row0=0, vocab_override=Non
     B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS[wl][:8]
     vocab = vocab_override or vocab
     rows = rows or B
+    # the ids are always drawn for the WHOLE global batch and then sliced: the generators draw several arrays one after the other,
+    # so a draw of fewer rows would give different values for the same rows (sharded must equal unsharded, row for row)
+    full = max(B, row0 + rows)
     Dt = WORKLOADS[wl][8] if mode == "concat_linear" else D
     g = torch.Generator(device=device).manual_seed(12345)                       # tables are replicated: same on every rank
     tok_table = torch.randn((vocab, Dt), generator=g, device=device, dtype=torch.float32)
@@ -189,7 +192,7 @@ def make_inputs(wl, device, seed, uniform, rows=None, row0=0, vocab_override=Non
         except FileNotFoundError:
             tab = gi.synth_ttb(5, vocab, bpt, "left")
             ttb_kind = "synthetic"
-        toks = gi.fineweb_like_tokens(seed, row0 + rows, T, vocab=vocab, uniform=uniform)[row0:]
+        toks = gi.fineweb_like_tokens(seed, full, T, vocab=vocab, uniform=uniform)[row0:row0 + rows]
         weight = None
         if mode == "concat_linear":
             K = Dt + bpt * Db
@@ -197,12 +200,12 @@ def make_inputs(wl, device, seed, uniform, rows=None, row0=0, vocab_override=Non
             weight = (torch.rand((D, K), generator=g, device=device, dtype=torch.float32) * 2 - 1) * bound
         return dict(toks=toks, tab=tab, tok_table=tok_table, byte_table=byte_table, ttb_kind=ttb_kind, weight=weight)
     if mode == "dual":   # no counterpart in the reference: synthetic ids, both vocabularies FineWeb-shaped
-        toks = gi.fineweb_like_tokens(seed, row0 + rows, T, vocab=vocab, uniform=uniform)[row0:]
-        ids2 = gi.fineweb_like_tokens(seed + 7, row0 + rows, T, vocab=Vb, uniform=uniform)[row0:].astype(np.int64)
+        toks = gi.fineweb_like_tokens(seed, full, T, vocab=vocab, uniform=uniform)[row0:row0 + rows]
+        ids2 = gi.fineweb_like_tokens(seed + 7, full, T, vocab=Vb, uniform=uniform)[row0:row0 + rows].astype(np.int64)
         return dict(toks=toks, chars=ids2, tok_table=tok_table, byte_table=byte_table, ttb_kind="n/a (second id tensor given)")
     rs = np.random.RandomState(seed)
-    toks = rs.randint(0, vocab, size=(row0 + rows, T)).astype(np.int32)[row0:]
-    chars = rs.randint(0, Vb, size=(row0 + rows, T * bpt)).astype(np.int64)[row0:]
+    toks = rs.randint(0, vocab, size=(full, T)).astype(np.int32)[row0:row0 + rows]
+    chars = rs.randint(0, Vb, size=(full, T * bpt)).astype(np.int64)[row0:row0 + rows]
     return dict(toks=toks, chars=chars, tok_table=tok_table, byte_table=byte_table, ttb_kind="n/a")
 
 
@@ -567,20 +570,42 @@ def main(argv=None):
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
         if args.backward and mode == "sum":
             from mixture_of_tokenizers_amd import data_creation as dc
+            F = mot.functional
             ids_b = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
             gout = torch.randn_like(out)
             into = {"tok_table": torch.zeros_like(inp["tok_table"], dtype=torch.float32),     # gradients are fp32 for bf16 tables too
                     "byte_table": torch.zeros_like(inp["byte_table"], dtype=torch.float32)}
-            bstep = lambda: mot.functional.embed_mix_backward(gout, toks, inp["tok_table"], inp["byte_table"], mode="sum",
-                                                               bpt=bpt, ids_a=ids_b, norm_out=True, into=into)
-            bms = timed_launches(bstep, max(1, args.steps // 4), warm=3)
+            bkw = dict(mode="sum", bpt=bpt, ids_a=ids_b, norm_out=True, into=into)
+            nb = max(1, args.steps // 4)
+            # (a) as the autograd node runs it: the positions were grouped by token beside the forward (mot_token_order on a side
+            #     stream), the backward call is the scatter kernel alone; (b) the grouping by itself; (c) a backward that groups
+            #     the positions itself (round 2's figure); (d) forward + grouping on two streams against the forward alone
+            order = F.token_order(toks, inp["tok_table"].shape[0])
+            bms = timed_launches(lambda: F.embed_mix_backward(gout, toks, inp["tok_table"], inp["byte_table"], token_order=order, **bkw), nb, warm=3)
+            oms = timed_launches(lambda: F.token_order(toks, inp["tok_table"].shape[0]), nb, warm=3)
+            sms = timed_launches(lambda: F.embed_mix_backward(gout, toks, inp["tok_table"], inp["byte_table"], **bkw), nb, warm=3)
+            side = torch.cuda.Stream(device=device)
+
+            def fwd_and_order():
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    F.token_order(toks, inp["tok_table"].shape[0])
+                plan()
+                torch.cuda.current_stream(device).wait_stream(side)
+
+            fms = timed_launches(plan, nb, warm=3)
+            foms = timed_launches(fwd_and_order, nb, warm=3)
             read_bytes = 2 * out.element_size() * D * tokens_per_step   # grad_out row + token row per position (byte rows and ids come from L2)
-            res["backward"] = {"kernel": "embed_mix_bwd_full_kernel", "kernel_ms": bms, "tokens_per_s": tokens_per_step / (bms * 1e-3),
+            kname = "embed_mix_bwd_plain_kernel" if args.dtype == "f32" else "embed_mix_bwd_full_kernel"
+            res["backward"] = {"kernel": kname, "kernel_ms": bms, "tokens_per_s": tokens_per_step / (bms * 1e-3),
                                "hbm_read_GBps": read_bytes / (bms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
-                               "note": "whole backward call: positions grouped by token with a counting sort (bwd_rank / bwd_scan / bwd_place), "
-                                       "then one scatter kernel -- a token row is read and its gradient row flushed (fp32 atomic "
-                                       "row-add) once per run, byte-table gradient in 64-bit fixed point in LDS; hbm_read counts the "
-                                       "algorithmic grad_out row + token row per position"}
+                               "token_order_ms": oms, "backward_grouping_itself_ms": sms,
+                               "forward_ms": fms, "forward_plus_token_order_on_a_side_stream_ms": foms,
+                               "note": "kernel_ms: the backward call with the positions already grouped by token (mot_token_order: a counting "
+                                       "sort, bwd_rank / bwd_scan / bwd_place, run once per batch beside the forward) = one scatter kernel: a "
+                                       "token row is read and its gradient row flushed (fp32 atomic row-add) once per run, byte-table "
+                                       "gradient in 64-bit fixed point in LDS; backward_grouping_itself_ms = the same call without a given "
+                                       "order; hbm_read counts the algorithmic grad_out row + token row per position"}
         if world == 1 and mode == "sum" and wl == "c4" and args.ids == "fused" and not args.uniform_ids and not args.no_extra:
             del plan, plan_cnt, out
             torch.cuda.empty_cache()

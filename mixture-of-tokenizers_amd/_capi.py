@@ -31,7 +31,7 @@ MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32, BF16 = 0, 1
 MAX_BPT = 64
-ABI_VERSION = 9
+ABI_VERSION = 10
 FLAG_LINEAR_ONE_LAUNCH, FLAG_MEAN_GENERIC, FLAG_BWD_DU_FP32, FLAG_LINEAR_COMPOSED = 1, 2, 4, 8
 HEADS_AS_VIEWED, HEADS_PER_TOKEN = 0, 1
 
@@ -46,7 +46,7 @@ def dtype_code(t: torch.dtype) -> int:
 EXPORTS = (
     "mot_version", "mot_last_error", "mot_build_info", "mot_tokens_to_bytes", "mot_pull_bytes",
     "mot_create_batch", "mot_char_matrix", "mot_gather_rows", "mot_embed_mix_desc_size", "mot_embed_mix_workspace_bytes",
-    "mot_embed_mix_fwd", "mot_embed_mix_bwd_workspace_bytes", "mot_embed_mix_bwd",
+    "mot_embed_mix_fwd", "mot_embed_mix_bwd_workspace_bytes", "mot_embed_mix_bwd", "mot_token_order_ints", "mot_token_order",
     "mot_cross_attn_desc_size", "mot_cross_attn_workspace_bytes", "mot_cross_attn_fwd",
     "mot_cross_attn_bwd_workspace_bytes", "mot_cross_attn_bwd",
     "mot_char_swa_desc_size", "mot_char_swa_workspace_bytes", "mot_char_swa_fwd",
@@ -79,7 +79,7 @@ class MotEmbedMixGrads(C.Structure):
     _fields_ = [
         ("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("grad_out", C.c_void_p),
         ("d_tok_table", C.c_void_p), ("d_byte_table", C.c_void_p), ("d_weight", C.c_void_p), ("d_bias", C.c_void_p),
-        ("d_scale_tok", C.c_void_p), ("d_scale_byte", C.c_void_p),
+        ("d_scale_tok", C.c_void_p), ("d_scale_byte", C.c_void_p), ("token_order", C.c_void_p),
     ]
 
 
@@ -143,6 +143,9 @@ def _load() -> C.CDLL:
     lib.mot_embed_mix_bwd_workspace_bytes.restype = C.c_size_t
     lib.mot_embed_mix_bwd_workspace_bytes.argtypes = [C.POINTER(MotEmbedMixDesc)]
     lib.mot_embed_mix_bwd.argtypes = [C.POINTER(MotEmbedMixDesc), C.POINTER(MotEmbedMixGrads), vp]
+    lib.mot_token_order_ints.restype = C.c_size_t
+    lib.mot_token_order_ints.argtypes = [i64, i64]
+    lib.mot_token_order.argtypes = [vp, i64, i64, vp, vp, vp]
     lib.mot_cross_attn_desc_size.restype = C.c_size_t
     lib.mot_cross_attn_workspace_bytes.restype = C.c_size_t
     lib.mot_cross_attn_workspace_bytes.argtypes = [C.POINTER(MotCrossAttnDesc)]

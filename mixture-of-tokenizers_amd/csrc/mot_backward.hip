@@ -1353,7 +1353,9 @@ __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const B
 template <int MODE>
 static bool plain_layout(const BwdArgs &A) {
     if (A.norm_tok || A.norm_byte || A.scale_tok || A.scale_byte || A.d_scale_tok || A.d_scale_byte || A.ids_b) return false;
-    if (MODE == MOT_MIX_SUM && (A.Db & 3)) return false;        // a 16-byte chunk of a row lies inside one byte slot
+    if (MODE == MOT_MIX_SUM && ((A.Db & 3) || A.Db > 128)) return false;   // a 16-byte chunk of a row lies inside one byte slot; wide byte rows
+                                                                            // (the D-wide "slot" of the cross-attention mixin's two-id backward) do
+                                                                            // not fit LDS, and this kernel's path for rows without an LDS slot is slow
     const int ne = A.D / 64;
     return ne == 4 || ne == 8 || ne == 12;   // 16 and up: seven row buffers no longer fit 128 registers
 }
@@ -1622,7 +1624,9 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     }
     // LDS besides the privatised byte-table sums: per-wave per-slot accumulators (strided kernels) or per-wave transposition rows (lane-contiguous)
     size_t lds = lc ? (size_t)(plain ? kPlWaves : kLcWaves) * A.D * sizeof(float) + 16 : 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
-    if ((rc = launch_group_positions(A.tokens, A.n_tokens, A.tok_rows, ws_ints, &A.pos_sorted, &A.tok_sorted, A.status, stream))) return rc;
+    // the positions grouped by token id: given by the caller (mot_token_order, same layout as the workspace) or made here
+    if (A.pos_sorted == nullptr || A.tok_sorted == nullptr)
+        if ((rc = launch_group_positions(A.tokens, A.n_tokens, A.tok_rows, ws_ints, &A.pos_sorted, &A.tok_sorted, A.status, stream))) return rc;
 #ifdef MOT_DEV_ABLATION
     if (getenv("MOT_BWD_SORT_ONLY")) return MOT_OK;  // dev: inspect the sort prologue's workspace from the host
 #endif
@@ -1662,6 +1666,12 @@ static void fill_bwd_args(BwdArgs &A, const MotEmbedMixDesc &d, const MotEmbedMi
     A.d_tok = (float *)gr.d_tok_table; A.d_byte = (float *)gr.d_byte_table;
     A.d_scale_tok = gr.d_scale_tok; A.d_scale_byte = gr.d_scale_byte;
     A.status = d.status;
+    A.pos_sorted = A.tok_sorted = nullptr;
+    if (gr.token_order) {   // [counts: rows][starts: rows][rank: n][pos_sorted: n][tok_sorted: n], as launch_group_positions lays it out
+        const int64_t n = d.n_rows * d.tokens_per_row;
+        A.pos_sorted = gr.token_order + 2 * d.tok_rows + n;
+        A.tok_sorted = A.pos_sorted + n;
+    }
     A.Dt = d.tok_dim; A.tok_lo = 0; A.byte_lo = 0; A.nbk = d.bpt * d.byte_dim;
 }
 

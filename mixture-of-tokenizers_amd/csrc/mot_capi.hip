@@ -183,6 +183,19 @@ size_t mot_embed_mix_workspace_bytes(const MotEmbedMixDesc *desc) {
     return embed_mix_workspace_bytes(*desc);
 }
 
+size_t mot_token_order_ints(int64_t n_tokens, int64_t tok_rows) {
+    if (n_tokens < 0 || tok_rows < 1) return 0;
+    return group_positions_ws_ints(n_tokens, tok_rows);
+}
+
+int mot_token_order(const int32_t *tokens, int64_t n_tokens, int64_t tok_rows, int32_t *order, uint32_t *status, mot_stream_t stream) {
+    if (n_tokens < 0 || tok_rows < 1 || n_tokens > 0x7fffffffLL) return set_error(MOT_EINVAL, "token_order: bad sizes");
+    if (n_tokens == 0) return MOT_OK;
+    if (!tokens || !order) return set_error(MOT_EINVAL, "token_order: null pointer");
+    const int32_t *pos, *ids;
+    return launch_group_positions(tokens, n_tokens, tok_rows, order, &pos, &ids, status, (hipStream_t)stream);
+}
+
 size_t mot_embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc *desc) {
     if (!desc || desc->struct_size != sizeof(MotEmbedMixDesc)) return 0;
     return embed_mix_bwd_workspace_bytes(*desc);

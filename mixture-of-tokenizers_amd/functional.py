@@ -324,6 +324,61 @@ def embed_mix_plan(tokens, tok_table, byte_table=None, **kw) -> EmbedMixPlan:
     return _embed_mix_fwd(tokens, tok_table, byte_table, _plan=True, **kw)
 
 
+@torch.compiler.disable
+def token_order(tokens: torch.Tensor, tok_rows: int) -> torch.Tensor:
+    """One call of mot_token_order: the batch's positions grouped by token id (opaque int32 buffer), which the table-gradient
+    scatter of every backward over these tokens walks.  Depends on `tokens` only; runs on the current stream."""
+    dev = capi.require_device(tokens)
+    tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
+    tok = tok if tok.is_contiguous() else tok.contiguous()
+    order = torch.empty(capi.lib.mot_token_order_ints(tok.numel(), int(tok_rows)), dtype=torch.int32, device=dev)
+    capi.check(capi.lib.mot_token_order(capi.ptr(tok), tok.numel(), int(tok_rows), capi.ptr(order), capi.ptr(capi.status_word(dev)),
+                                        capi.stream_of(dev)))
+    capi.after_call(dev)
+    return order
+
+
+class _TokenOrderCache:
+    """The token order of the last few token tensors seen by the autograd node, produced BESIDE the forward: on a side stream that
+    waits for the tokens and runs while the forward kernel streams (the sort is three small latency-bound kernels, the forward is
+    HBM-bound), so the backward finds it ready instead of spending 0.08 ms of a 0.55 ms call on it.  One order serves every
+    backward over the same tokens: several embedding tables indexed by one token tensor (modded-nanogpt/runs/71_*.py value
+    embeddings), gradient accumulation, the two front-ends of a mixin/mixout pair.  An entry is valid for the SAME tensor object
+    at the SAME version with the same table height; entries keep their token tensor alive (a few MB), so an address cannot be
+    reused under a stale entry."""
+
+    def __init__(self, keep: int = 4):
+        self.keep, self.entries, self.side = keep, [], {}
+
+    def get(self, tokens: torch.Tensor, tok_rows: int):
+        for e in self.entries:
+            if e[0] is tokens and e[1] == tokens._version and e[2] == tok_rows:
+                return e[3], e[4]
+        dev = tokens.device
+        cur = torch.cuda.current_stream(dev)
+        if torch.cuda.is_current_stream_capturing():          # inside a graph capture: no side stream, the sort is captured in line
+            order, ev = token_order(tokens, tok_rows), None
+        else:
+            side = self.side.get(dev.index)
+            if side is None:
+                side = self.side[dev.index] = torch.cuda.Stream(device=dev)
+            side.wait_stream(cur)                              # the tokens are ready when the current stream gets here
+            with torch.cuda.stream(side):
+                order = token_order(tokens, tok_rows)
+                ev = torch.cuda.Event()
+                ev.record(side)
+        self.entries.insert(0, (tokens, tokens._version, tok_rows, order, ev))
+        del self.entries[self.keep:]
+        return order, ev
+
+    def clear(self):
+        self.entries.clear()
+
+
+_token_orders = _TokenOrderCache()
+_HOIST_SORT = not os.environ.get("MOT_NO_ORDER_HOIST")            # dev switch: let every backward group the positions itself
+
+
 _BWD_MODES = ("sum", "noop", "concat_linear", "mean")
 
 
@@ -352,6 +407,8 @@ class _EmbedMixFn(torch.autograd.Function):
         if want_ids:   # the byte ids the kernel produced in LDS, written out once for the backward
             ids_a = r.ids_pulled if kw.get("pull") not in (None, "none") else r.ids_padded
             ids_b = r.ids_padded if kw.get("add_padded") else None
+        # the positions grouped by token id, for the backward: requested here so that it runs beside the forward launch above
+        ctx.order = _token_orders.get(tokens, tok_table.shape[0]) if _HOIST_SORT else None
         ctx.save_for_backward(tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b, weight, bias,
                               x if mode == "concat_linear" else None, rn)
         ctx.kw = {k: kw[k] for k in ("mode", "bpt", "norm_tok", "norm_byte", "norm_out", "eps", "bytes_first") if k in kw}
@@ -368,8 +425,14 @@ class _EmbedMixFn(torch.autograd.Function):
         # else gets a fresh fp32 gradient handed to autograd as usual.
         direct = {k: p.grad for k, p in (("tok_table", tok_table), ("byte_table", byte_table), ("weight", weight), ("bias", bias))
                   if _accumulates_in_place(p)}
+        order = None
+        if ctx.order is not None:
+            order, ev = ctx.order
+            if ev is not None:
+                torch.cuda.current_stream(gx.device).wait_event(ev)
+            order.record_stream(torch.cuda.current_stream(gx.device))
         g = embed_mix_backward(gx, tokens, tok_table.detach(), None if byte_table is None else byte_table.detach(),
-                               ids_a=ids_a, ids_b=ids_b,
+                               ids_a=ids_a, ids_b=ids_b, token_order=order,
                                scale_tok=None if scale_tok is None else scale_tok.detach(),
                                scale_byte=None if scale_byte is None else scale_byte.detach(),
                                weight=None if weight is None else weight.detach(), bias=None if bias is None else bias.detach(),
@@ -396,11 +459,13 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
                        scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None,
                        weight: torch.Tensor | None = None, bias: torch.Tensor | None = None, bytes_first: bool = False,
                        out: torch.Tensor | None = None, row_rnorm: torch.Tensor | None = None,
-                       into: dict | None = None, du_fp32: bool | None = None, one_launch: bool | None = None) -> dict:
+                       into: dict | None = None, du_fp32: bool | None = None, one_launch: bool | None = None,
+                       token_order: torch.Tensor | None = None) -> dict:
     """One launch of mot_embed_mix_bwd.  Returns dense fp32 gradients {tok_table, byte_table, scale_tok,
     scale_byte, weight, bias} -- fp32 also when the tables are bfloat16 (accumulated in fp32; the autograd
     node rounds once to the parameter dtype); pass `into` (same keys, fp32) to accumulate into existing
-    buffers such as ``param.grad``."""
+    buffers such as ``param.grad``.  `token_order`: what :func:`token_order` returned for these tokens and this table height (the
+    caller orders streams); without it the call groups the positions itself."""
     m = _MODES[mode]
     if tokens.ndim == 1:
         tokens = tokens[None]
@@ -468,6 +533,12 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
         if sc is not None and out[k] is None:
             out[k] = torch.zeros(1, dtype=torch.float32, device=dev)
     gr.d_scale_tok, gr.d_scale_byte = capi.ptr(out["scale_tok"]), capi.ptr(out["scale_byte"])
+    if token_order is not None:
+        need = capi.lib.mot_token_order_ints(B * T, tt.shape[0])
+        if token_order.dtype != torch.int32 or token_order.numel() != need or token_order.device != dev or not token_order.is_contiguous():
+            raise ValueError(f"token_order must be the contiguous int32[{need}] tensor token_order(tokens, {tt.shape[0]}) returned")
+        gr.token_order = capi.ptr(token_order)
+        keep.append(token_order)
     d.status = capi.ptr(capi.status_word(dev))
     ws = _workspace(dev, capi.lib.mot_embed_mix_bwd_workspace_bytes(C.byref(d)))
     if ws is not None:

@@ -562,3 +562,72 @@ def test_sum_backward_non_finite_gradient_reaches_the_byte_table(mot, kw):
     assert np.isnan(host(got["tok_table"])[toks[0, 0]]).any()
     clean = np.setdiff1d(np.arange(256), [])                    # rows 0..255 are shared with healthy positions only
     assert np.isfinite(gb[clean]).all()
+
+
+def test_token_order_given_or_not(mot):
+    """mot_token_order once per batch + backward calls that are handed the order (what the autograd node does) against backward
+    calls that group the positions themselves and against the float64 oracle; the order buffer's sorted arrays are a permutation
+    of the positions with non-decreasing token ids, every position exactly once."""
+    D, Db, bpt, Vt, B, T, seed = 768, 48, 16, 3000, 6, 700, 9401
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left")
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    g = f32(np.random.RandomState(seed + 4).standard_normal((B, T, D)))
+    pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+    F = mot.functional
+    dtoks = dev(toks)
+    order = F.token_order(dtoks, Vt)
+    n = B * T
+    o = host(order)
+    assert o.size == 2 * Vt + 3 * n
+    pos_sorted, tok_sorted = o[2 * Vt + n:2 * Vt + 2 * n], o[2 * Vt + 2 * n:]
+    assert np.array_equal(np.sort(pos_sorted), np.arange(n)) and (np.diff(tok_sorted) >= 0).all()
+    assert np.array_equal(toks.reshape(-1)[pos_sorted], tok_sorted)
+    for kw in (dict(norm_out=True), dict(norm_tok=True, norm_byte=True, norm_out=True)):
+        ref = orc.embed_mix_bwd(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt,
+                                dtype=np.float64, **kw)
+        a = F.embed_mix_backward(dev(g), dtoks, dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(pulled), token_order=order, **kw)
+        b = F.embed_mix_backward(dev(g), dtoks, dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(pulled), **kw)
+        for k in ("tok_table", "byte_table"):
+            assert rel(host(a[k]), ref[k]) < TOL and rel(host(b[k]), ref[k]) < TOL
+    ref = orc.embed_mix_bwd(toks, None, None, Et.astype(np.float64), None, g.astype(np.float64), mode="noop", bpt=0, dtype=np.float64, norm_tok=True)
+    a = F.embed_mix_backward(dev(g), dtoks, dev(Et), mode="noop", norm_tok=True, token_order=order)
+    assert rel(host(a["tok_table"]), ref["tok_table"]) < TOL
+    with pytest.raises(ValueError, match="token_order"):
+        F.embed_mix_backward(dev(g), dtoks, dev(Et), mode="noop", norm_tok=True, token_order=order[:-1])
+
+
+def test_autograd_reuses_the_token_order_per_token_tensor(mot):
+    """The autograd node asks for the token order beside the forward (side stream) and keeps it per token TENSOR and version: a
+    second forward + backward over the same tensor reuses it, an in-place change of the tokens makes a new one; gradients match
+    the oracle every time (a stale order would scatter rows to the wrong tokens)."""
+    D, Db, bpt, Vt, B, T, seed = 256, 32, 8, 700, 4, 300, 9411
+    F = mot.functional
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left")
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    g = f32(np.random.RandomState(seed + 4).standard_normal((B, T, D)))
+    pt, pb = torch.nn.Parameter(dev(Et)), torch.nn.Parameter(dev(Eb))
+    toks_a = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.01)
+    toks_b = gi.fineweb_like_tokens(seed + 9, B, T, vocab=Vt, eot_p=0.01)
+    dtoks = dev(toks_a)
+    F._token_orders.clear()
+
+    def run(toks_np):
+        pt.grad = pb.grad = None
+        x = mot.embed_mix(dtoks, pt, pb, mode="sum", bpt=bpt, ttb=dev(tab), pull="left", norm_out=True)
+        x.backward(dev(g))
+        torch.cuda.synchronize()
+        pulled = orc.pull_from_left(orc.tokens_to_bytes(toks_np, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
+        ref = orc.embed_mix_bwd(toks_np, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt,
+                                dtype=np.float64, norm_out=True)
+        assert rel(host(pt.grad), ref["tok_table"]) < TOL and rel(host(pb.grad), ref["byte_table"]) < TOL
+
+    run(toks_a)
+    assert len(F._token_orders.entries) == 1
+    first = F._token_orders.entries[0][3]
+    run(toks_a)
+    assert len(F._token_orders.entries) == 1 and F._token_orders.entries[0][3] is first      # reused
+    dtoks.copy_(dev(toks_b))                                                                  # same tensor, new version
+    run(toks_b)
+    assert F._token_orders.entries[0][3] is not first
+    mot.check_status()

@@ -333,3 +333,21 @@ def test_bench_visible_gpus_reads_sysfs_only(monkeypatch, tmp_path):
     assert bench.visible_gpus() == 2
     monkeypatch.setattr(bench, "Path", lambda p: tmp_path / "missing" if str(p) == "/sys/class/kfd/kfd/topology/nodes" else real_path(p))
     assert bench.visible_gpus() is None
+
+
+def test_bench_rank_slices_are_rows_of_the_one_global_batch():
+    """Strong scaling in bench.py: rank r's tokens ARE rows [r*B/W, (r+1)*B/W) of the batch a single GPU runs (the id generators
+    draw several arrays in a row, so they must always draw the whole batch and slice; found by the two-rank GPU rehearsal)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_slices", REPO / "bench.py")
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cpu = torch.device("cpu")
+    for wl in ("c2", "c3"):
+        B = bench.WORKLOADS[wl][0]
+        whole = bench.make_inputs(wl, cpu, 12345, False)
+        for world in (2, 4):
+            parts = [bench.make_inputs(wl, cpu, 12345, False, rows=B // world, row0=r * (B // world)) for r in range(world)]
+            np.testing.assert_array_equal(np.concatenate([p["toks"] for p in parts]), whole["toks"])
+            if "chars" in whole:
+                np.testing.assert_array_equal(np.concatenate([p["chars"] for p in parts]), whole["chars"])
