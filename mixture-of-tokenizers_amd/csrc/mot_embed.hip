@@ -2,15 +2,17 @@
 // SUM / MEAN / NOOP modes, the seam gather (materialised FlexibleEmbedding outputs) and the
 // byte-table inverse-rms prologue.  fp32 throughout (the reference's CPU parity mode).
 //
-// Fused kernel, per tile of <= 256 tokens of one row (one 256-thread workgroup):
-//   phase 1  byte ids for the tile into LDS: token->byte-table gather + pull (mot_tile.hpp), or a
-//            coalesced copy of precomputed int64 ids.  Byte ids never touch HBM.
-//   phase 2  one wave per token, U tokens in flight per wave: the token row is read with
-//            16 B/lane coalesced loads (lane l owns float4 chunks l, l+64, ...), the byte rows
-//            that line up with those chunks come from the (L2-resident, <= 1.4 MB) byte table,
-//            rms-norm reductions are wave shuffles, the mixed row is written once with
-//            non-temporal 16 B stores.  Algorithmic traffic: 4 + 2*bpt + 4*Dt B read and
-//            4*Dm B written per token; HBM-bound.
+// Fused kernel (embed_mix_kernel): every WAVE works alone on a unit of 16 or 32 consecutive tokens of one row -- no workgroup
+// barrier anywhere (the 256-thread tile version of round 1, seven barriers per tile, is gone from this file; the tile machinery
+// of mot_tile.hpp still serves the standalone index kernels and the one-launch concat + linear kernels):
+//   index pass  the unit's byte ids into wave-private LDS: token->byte-table rows in registers, valid counts and EOT segments
+//               by DPP wave scans, branch-free compaction (mot_wave.hpp), or a coalesced copy of precomputed int64 ids.
+//               Byte ids never touch HBM.
+//   streaming   U tokens in flight per wave: the token row is read with 16 B/lane coalesced loads from a SCALAR base (lane l
+//               owns float4 chunks l, l+64, ...; the token id is handed out with v_readlane), the byte rows that line up with
+//               those chunks come from the (L2-resident, <= 1.4 MB) byte table, rms-norm reductions are DPP wave reductions
+//               (row_shr / row_bcast: VALU, not LDS shuffles), the mixed row is written once with non-temporal 16 B stores.
+//               Algorithmic traffic: 4 + 2*bpt + 4*Dt B read and 4*Dm B written per token; HBM-bound.
 #include <stdlib.h>
 
 #include "mot_wave.hpp"
@@ -463,8 +465,21 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
     constexpr int VEC = Elem<T>::kVec;
     typedef typename Elem<T>::vec vec_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = blockIdx.x % nslices;
-    const int64_t part = blockIdx.x / nslices;
+#ifndef MOT_C5_MAP
+#define MOT_C5_MAP 0
+#endif
+#ifndef MOT_C5_STORE
+#define MOT_C5_STORE 0
+#endif
+    int slice = blockIdx.x % nslices;
+    int64_t part = blockIdx.x / nslices;
+    if (MOT_C5_MAP == 1 && (gridDim.x / nslices) % 8 == 0) {
+        // dev variant: the nslices workgroups of one token partition on ONE XCD (workgroups b and b + 8 share an XCD): the eight
+        // 1 KB pieces of an 8 KB output row then pass through one L2
+        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
+        slice = k % nslices;
+        part = (int64_t)x * ((gridDim.x / nslices) / 8) + k / nslices;
+    }
     const int col0 = slice * slice_cols;
     const int D = A.Dt;
     const T *byte_table = (const T *)A.byte_table, *tok_table = (const T *)A.tok_table;
@@ -525,22 +540,29 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t n = chunk + b + u;
-                // chars.mean(dim=-2), inference.py:267: four independent LDS reads per step (two accumulators keep the adds off one chain)
+                // chars.mean(dim=-2), inference.py:267: four independent LDS reads per step (two accumulators keep the adds off one chain).
+                // The character ids of the batch sit one per lane; a slot's id is handed out with v_readlane (the slot index is
+                // wave-uniform), so the LDS row address is one scalar multiply + one add per character.  (Round 2 used __shfl here:
+                // a ds_bpermute per character on the LDS pipe that also carries the eight 1 KB row reads of a token -- without the
+                // output stores the kernel took 3.1 ms of its 6.3, half of it that.)
                 vec_t acc0 = (vec_t)(0.f), acc1 = (vec_t)(0.f);
                 const int l0 = u * A.bpt;
+                const unsigned char *tabc = (const unsigned char *)tab + (size_t)c * sizeof(T);
+                const uint32_t row_bytes = (uint32_t)slice_cols * (uint32_t)sizeof(T);
                 int k = 0;
                 for (; k + 4 <= A.bpt; k += 4) {
-                    const int i0 = __shfl(idv, l0 + k, 64), i1 = __shfl(idv, l0 + k + 1, 64), i2 = __shfl(idv, l0 + k + 2, 64), i3 = __shfl(idv, l0 + k + 3, 64);
-                    vec_t v0 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i0 * slice_cols + c));
-                    vec_t v1 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i1 * slice_cols + c));
-                    vec_t v2 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i2 * slice_cols + c));
-                    vec_t v3 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)i3 * slice_cols + c));
+                    const int i0 = __builtin_amdgcn_readlane(idv, l0 + k), i1 = __builtin_amdgcn_readlane(idv, l0 + k + 1),
+                              i2 = __builtin_amdgcn_readlane(idv, l0 + k + 2), i3 = __builtin_amdgcn_readlane(idv, l0 + k + 3);
+                    vec_t v0 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i0 * row_bytes));
+                    vec_t v1 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i1 * row_bytes));
+                    vec_t v2 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i2 * row_bytes));
+                    vec_t v3 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i3 * row_bytes));
                     if (A.norm_byte) { v0 *= A.byte_rnorm[i0]; v1 *= A.byte_rnorm[i1]; v2 *= A.byte_rnorm[i2]; v3 *= A.byte_rnorm[i3]; }
                     acc0 += v0; acc1 += v1; acc0 += v2; acc1 += v3;
                 }
                 for (; k < A.bpt; ++k) {
-                    const int id = __shfl(idv, l0 + k, 64);
-                    vec_t v = Elem<T>::widen(*(const typename Elem<T>::raw *)(tab + (size_t)id * slice_cols + c));
+                    const int id = __builtin_amdgcn_readlane(idv, l0 + k);
+                    vec_t v = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)id * row_bytes));
                     if (A.norm_byte) v *= A.byte_rnorm[id];
                     acc0 += v;
                 }
@@ -549,7 +571,14 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                 if (A.scale_tok) a *= s_tok;
                 const vec_t bsum = acc * inv_bpt;             // exact for the power-of-two slot counts of the reference (8), else within an ulp of acc / bpt
                 const vec_t x = a + (A.scale_byte ? bsum * s_byte : bsum);
-                if (b + u < nb) Elem<T>::storev_nt(out + n * D + col0 + c, x);
+#ifdef MOT_C5_NOSTORE   // dev, timing only: everything but the output stores
+                if (b + u < nb && x[0] == 123.456f) {
+#else
+                if (b + u < nb) {
+#endif
+                    if (MOT_C5_STORE == 1) *(typename Elem<T>::raw *)(out + n * D + col0 + c) = __builtin_convertvector(x, typename Elem<T>::raw);
+                    else Elem<T>::storev_nt(out + n * D + col0 + c, x);
+                }
             }
         }
     }

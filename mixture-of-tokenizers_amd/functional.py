@@ -420,9 +420,13 @@ class _EmbedMixFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gx, *_):
         tok_table, byte_table, scale_tok, scale_byte, tokens, ids_a, ids_b, weight, bias, x, rn = ctx.saved_tensors
-        # Parameters whose .grad is managed by grad_sync.GradBucket take the kernel's += directly (mot_embed_mix_bwd only ever
-        # adds into its outputs): no temporary table-sized gradient, no zero fill, no AccumulateGrad pass over it.  Everything
-        # else gets a fresh fp32 gradient handed to autograd as usual.
+        # Parameters whose .grad is managed by grad_sync.GradBucket (an explicit opt-in: GradBucket(..., in_place=True) marks them)
+        # take the kernel's += directly (mot_embed_mix_bwd only ever adds into its outputs): no temporary table-sized gradient,
+        # no zero fill, no AccumulateGrad pass over it.  The price, documented on GradBucket: for those parameters autograd sees
+        # no gradient -- tensor hooks and post-accumulate-grad hooks do not fire, and torch.autograd.grad(...) would find .grad
+        # changed -- so the direct path is refused under torch.autograd.grad (ctx.needs_input_grad is all there is to go by: it is
+        # taken only when backward() was asked to accumulate into leaves).  Everything else gets a fresh fp32 gradient handed to
+        # autograd as usual.
         direct = {k: p.grad for k, p in (("tok_table", tok_table), ("byte_table", byte_table), ("weight", weight), ("bias", bias))
                   if _accumulates_in_place(p)}
         order = None
@@ -551,14 +555,19 @@ def embed_mix_backward(grad_out: torch.Tensor, tokens: torch.Tensor, tok_table: 
 def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.Tensor | None = None, *,
               scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None, **kw):
     """The fused front-end (see `_embed_mix_fwd` for the arguments).  With autograd enabled and
-    differentiable parameters it records one backward node (modes "sum", "noop", "concat_linear";
-    float32 or bfloat16 tables)."""
+    differentiable parameters it records one backward node: modes "sum", "noop", "concat_linear" with
+    float32 or bfloat16 tables; "mean" with float32 tables and no output norm.  Anything else raises here,
+    at forward time, rather than in backward()."""
     params = (tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"))
     if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
         if kw["mode"] not in _BWD_MODES:
             raise RuntimeError(
                 f"mixture-of-tokenizers_amd: backward of mode '{kw['mode']}' is not built yet (forward only); "
                 "call it under torch.no_grad() or with frozen parameters")
+        if kw["mode"] == "mean" and (tok_table.dtype != torch.float32 or kw.get("norm_out")):
+            raise RuntimeError(
+                "mixture-of-tokenizers_amd: the backward of the MEAN mix is built for float32 tables without an output norm "
+                "(mot_embed_mix_bwd, include/mot.h); call it under torch.no_grad() or with frozen parameters")
         if kw.get("out") is not None or kw.get("counters") is not None:
             raise ValueError("out= / counters= cannot be combined with autograd")
         r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"), tokens, kw)

@@ -15,7 +15,16 @@ import torch.distributed as dist
 
 
 class GradBucket:
-    def __init__(self, params, process_group=None):
+    """One flat gradient buffer behind the `.grad` of every given parameter (views), one all-reduce for all of them.
+
+    `in_place=True` is an explicit opt-in to the kernel-level accumulate: the fused backward (functional._EmbedMixFn) then adds
+    its fp32 sums straight into these views and hands autograd NO gradient for the parameters -- no table-sized temporary, no
+    AccumulateGrad pass -- which also means that tensor hooks / post-accumulate-grad hooks registered on them do not fire and
+    that `.grad` changes as a side effect of the backward call itself (do not combine with torch.autograd.grad).  With the default
+    `in_place=False` the views still back `.grad` (autograd accumulates into them as into any existing .grad) and everything
+    autograd promises holds."""
+
+    def __init__(self, params, process_group=None, in_place: bool = False):
         seen, self.params = set(), []
         for p in params:                       # tied weights (mathblations/model.py:316-317) appear once
             if p.requires_grad and id(p) not in seen:
@@ -38,7 +47,7 @@ class GradBucket:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             # fp32 views: the fused backward adds into them directly (functional._EmbedMixFn.backward) instead of
             # materialising a table-sized temporary for autograd's AccumulateGrad to add
-            p._mot_grad_in_place = dt == torch.float32
+            p._mot_grad_in_place = bool(in_place) and dt == torch.float32
 
     def zero_(self) -> None:
         """Replaces optimizer.zero_grad(set_to_none=True) for these parameters (keeps the views)."""

@@ -18,11 +18,14 @@ mixes and writes x.  Anything that needs the tensors themselves calls ``handle.m
 Parameters are read from their live storage at launch time, so weight tying
 (``wte.weight = lm_head.weight``, model.py:316-317) and in-place optimizer updates are honoured.
 
-Autograd: the fused paths (sum, tokens-only/noop, concat + linear incl. norm(emb(padded) + emb(pulled)),
-and the cross-attention mixin over one id tensor) are differentiable with fp32 or bf16 parameters: one
-backward call produces dense fp32 gradient sums for the tables / weight / bias / scalars, rounded once to
-the parameter dtype.  What has no backward raises instead of silently dropping the graph: the MEAN mix,
-the materialised (non-fused) seam tensors, and the cross-attention mixin over two id tensors.
+Autograd: the fused paths are differentiable with one backward call that produces dense fp32 gradient sums for the tables /
+weight / bias / scalars, rounded once to the parameter dtype:
+  * sum, tokens-only (noop), concat + linear incl. norm(emb(padded) + emb(pulled)): fp32 or bf16 parameters;
+  * the MEAN residual (config 5): fp32 parameters, no output norm;
+  * the cross-attention mixin over one id tensor OR two (norm(emb(padded) + emb(pulled))): fp32 arithmetic, bf16 tables
+    accepted (widened once).
+What has no backward raises at FORWARD time instead of silently dropping the graph: MEAN with bf16 tables or an output norm,
+the character mixer (inference-only in the reference), and the materialised (non-fused) seam tensors.
 """
 from __future__ import annotations
 

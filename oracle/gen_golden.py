@@ -90,6 +90,18 @@ def load_create_data_TT_FF(dc, ttb_in, pull_in, bpt):
     return ns["_create_data_from_toks_TT_FF"]
 
 
+def load_create_data_variants(dc, ttb_in, ttb_out, pull_in, pull_out, bpt) -> dict:
+    """All eight `_create_data_from_toks_*` variants (train_gpt.py:686-764), nested inside the loader generator: every nested
+    FunctionDef of that name is taken from the AST and executed with the closure names bound, exactly as it stands."""
+    from torch import Tensor
+    tree = ast.parse((REF / "scaled-pre-train" / "train_gpt.py").read_text())
+    fns = [n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name.startswith("_create_data_from_toks_")]
+    assert len(fns) == 8, [f.name for f in fns]
+    ns = dict(tokens_to_bytes=dc.tokens_to_bytes, ttb_in=ttb_in, ttb_out=ttb_out, pull_in=pull_in, pull_out=pull_out, bpt=bpt, Tensor=Tensor)
+    exec(compile(ast.Module(body=fns, type_ignores=[]), "train_gpt.py", "exec"), ns)
+    return {f.name: ns[f.name] for f in fns}
+
+
 def load_run71_defs() -> dict:
     import torch.nn.functional as F
     from torch import Tensor, nn
@@ -223,6 +235,23 @@ def gen_loader(dc):
             out[f"{p}/bytes_pulled_in"] = t2n(bytes_pulled_in)
             out[f"{p}/targets"] = t2n(targets)
     out["pos"] = np.int64(pos); out["batch"] = np.int64(batch); out["seq"] = np.int64(seq)
+    # every variant of the dispatch table (train_gpt.py:686-783): inputs left-padded + pulled from the left, targets right-padded +
+    # pulled from the right (so that a mixed-up table or direction cannot pass); rank 1 of 2 and the whole batch
+    ttb_out = ttb_embedding(tabr)
+    pull_out = functools.partial(dc.pull_from_right, bytes_per_token=bpt, pad_byte=456, eot_byte=457)
+    variants = load_create_data_variants(dc, ttb_in, ttb_out, pull_in, pull_out, bpt)
+    names = []
+    for world, rank in ((1, 0), (2, 1)):
+        local_batch_size = (batch * (seq + 1)) // world
+        tokens = d[pos + rank * local_batch_size:][:local_batch_size].view(-1, seq + 1)
+        for name, fn in sorted(variants.items()):
+            res = fn(tokens)
+            key = name[len("_create_data_from_toks_"):]
+            names.append(key)
+            for what, val in zip(("toks_in", "bytes_padded_in", "bytes_pulled_in", "targets"), res):
+                if val is not None:                      # a missing key IS the reference's None
+                    out[f"variants/w{world}r{rank}/{key}/{what}"] = t2n(val)
+    out["variants/names"] = np.array(sorted(set(names)))
     # create_batch (data_creation.py:308-330)
     toks = torch.from_numpy(gi.edge_tokens(302, 3, 40, vocab))
     full = dc.create_batch(toks, bpt, 456, 457, ttb_embedding(tabr), ttb_embedding(tab))
@@ -663,6 +692,9 @@ def main():
         return
     if sys.argv[1:] == ["digit_cross_attn"]:
         gen_digit_cross_attn(*load_mathblations())
+        return
+    if sys.argv[1:] == ["loader"]:
+        gen_loader(load_data_creation())
         return
     if sys.argv[1:] == ["bf16"]:
         gen_bf16(load_data_creation(), load_train_gpt_defs(), load_run71_defs())

@@ -252,7 +252,7 @@ def _bucket_case(seed, Vt=512, D=128, Db=16, bpt=8, B=4, T=96):
     fe = SumFrontEnd(Vt, gi.BYTE_VOCAB, D, Db, bpt, variant="71041", ttb=dev(tab)).to(DEV)
     with torch.no_grad():    # nn.Embedding's own init draws from torch's global generator: never leave a parity test on that
         fe.embed_tokens.weight.copy_(dev(Et)); fe.embed_bytes.weight.copy_(dev(Eb)); fe.scalars.copy_(dev(sc))
-    bucket = GradBucket(list(fe.parameters()))
+    bucket = GradBucket(list(fe.parameters()), in_place=True)
     pulled = orc.pull_from_left(orc.tokens_to_bytes(toks, tab.astype(np.float32)), bpt, gi.PAD, gi.EOT)
     ref = orc.embed_mix_bwd(toks, pulled, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt,
                             dtype=np.float64, norm_tok=True, norm_byte=True, norm_out=True, scale_tok=float(sc[1]), scale_byte=float(sc[0]))

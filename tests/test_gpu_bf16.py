@@ -104,6 +104,46 @@ def test_bf16_limits(mot):
 
 
 
+def _concat_operand64(toks, ids, Et, Eb, bpt, norm_tok, norm_byte, eps=2.0 ** -7):
+    """The concat operand BEFORE its rounding to bf16, in float64: [norm?(E_t[tok]) | norm?(E_b[id_k]) ...] per token (either
+    order of the two parts holds the same elements).  eps is F.rms_norm's default for bf16 inputs."""
+    a = Et.astype(np.float64)[toks]                                            # (B, T, Dt)
+    b = Eb.astype(np.float64)[ids.reshape(toks.shape + (bpt,))]                # (B, T, bpt, Db)
+    if norm_tok:
+        a = a / np.sqrt((a ** 2).mean(-1, keepdims=True) + eps)
+    if norm_byte:
+        b = b / np.sqrt((b ** 2).mean(-1, keepdims=True) + eps)
+    return np.concatenate([a, b.reshape(toks.shape + (-1,))], -1)
+
+
+def _near_bf16_boundary(v, rel):
+    """True where a bf16 rounding boundary (the midpoint of two neighbouring bf16 values) lies within rel * |v| of v."""
+    av = np.abs(v)
+    e = np.floor(np.log2(np.maximum(av, 1e-300)))
+    step = 2.0 ** (e - 7)                                                      # bf16 spacing in [2^e, 2^(e+1))
+    frac = np.mod(av / step, 1.0)
+    return (np.abs(frac - 0.5) * step <= rel * av) & (av > 0)
+
+
+def _assert_excused_by_a_rounding_boundary(got, want, far, toks, ids, Et, Eb, bpt, kw):
+    """The noise floor of the concat tests is self-proving: an element that is MORE than two bf16 steps from
+    the oracle but inside the floor is excused only if its token really has a concat-operand element sitting on a bf16 rounding
+    boundary -- within 2^-20 relative, what the kernel's fp32 rms factor (v_rsq / v_rcp, <= 1 ulp each, and its summation order)
+    can move the product by -- and at most 1 % of the tokens may need the excuse.  Anything else is a kernel error."""
+    excused = (ulps(got, want) > 2) & ~far
+    tok_exc = excused.any(-1)
+    if not tok_exc.any():
+        return
+    if not (kw.get("norm_tok") or kw.get("norm_byte")):
+        raise AssertionError("elements beyond 2 bf16 steps although no operand element is computed (no per-embedding norm): nothing can sit on a boundary")
+    u = _concat_operand64(toks, ids, Et, Eb, bpt, bool(kw.get("norm_tok")), bool(kw.get("norm_byte")))
+    on_boundary = _near_bf16_boundary(u, 2.0 ** -20).any(-1)
+    bad = tok_exc & ~on_boundary
+    assert not bad.any(), f"{int(bad.sum())} tokens beyond 2 bf16 steps without an operand element on a rounding boundary, first at {np.argwhere(bad)[0]}"
+    assert tok_exc.mean() <= 0.01, f"{tok_exc.mean():.3%} of the tokens need the rounding-boundary excuse"
+
+
+
 # ------------------------------------------------------------------------------------------------
 # concat + linear in bf16 (bf16 MFMA, fp32 accumulate): the production dtype of ByteMixinConcat.
 # Oracle: float64 on the bf16-valued tables / weight with the concat operand rounded to bf16 (what F.linear
@@ -163,6 +203,7 @@ def test_bf16_concat_linear_vs_oracle(mot, path, Dt, Db, bpt, Dm, Vt, B, T, kw, 
     far = np.abs(got.astype(np.float64) - want) > noise
     assert ulps(got, want)[far].max(initial=0) <= 2
     assert (got == want).mean() > 0.97
+    _assert_excused_by_a_rounding_boundary(got, want, far, toks, pulled, Et, Eb, bpt, kw)
     # the same with the byte ids given (the module seam)
     xg = mot.embed_mix(dev(toks), b16(Et), b16(Eb), mode="concat_linear", bpt=bpt, ids_a=dev(pulled), weight=b16(W), bias=b16(bias),
                        **sel, **kw)
@@ -170,6 +211,7 @@ def test_bf16_concat_linear_vs_oracle(mot, path, Dt, Db, bpt, Dm, Vt, B, T, kw, 
     farg = np.abs(gotg.astype(np.float64) - want) > noise
     assert ulps(gotg, want)[farg].max(initial=0) <= 2
     assert (gotg == want).mean() > 0.97
+    _assert_excused_by_a_rounding_boundary(gotg, want, farg, toks, pulled, Et, Eb, bpt, kw)
 
 
 @pytest.mark.parametrize("B,T", [(3, 333), (9, 2003)], ids=["999_tokens", "18027_tokens"])   # 16 / 32 tokens per wave in the index pass
@@ -221,6 +263,7 @@ def test_bf16_concat_full_size_c2(mot):
     noise = np.maximum(5e-4, float(np.abs(W).max()) * 2.0 ** -5 / np.sqrt((y ** 2).mean(-1, keepdims=True) + 2.0 ** -7))   # see the test above
     far = np.abs(got.astype(np.float64) - want) > noise
     assert ulps(got, want)[far].max(initial=0) <= 2 and (got == want).mean() > 0.97
+    _assert_excused_by_a_rounding_boundary(got, want, far, toks[rows], pulled, Et, Eb, bpt, dict(norm_tok=True, norm_byte=True))
     x = r.x
     assert bool(torch.isfinite(x.float()).all())
     ms = (x.double() ** 2).mean(-1)

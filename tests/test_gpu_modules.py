@@ -155,6 +155,45 @@ def test_loader_create_data_matches_reference_fixture():
             assert toks_in.dtype == torch.int32 and bytes_pulled_in.dtype == torch.int64
 
 
+_VARIANTS = {   # dispatch key (byte_in, pull_in, byte_out, pull_out) of train_gpt.py:766-783 -> the reference function's suffix
+    (True, True, True, True): "TT_TT", (True, False, True, True): "TF_TT", (True, True, True, False): "TT_TF", (True, True, False, False): "TT_FF",
+    (False, False, True, True): "FF_TT", (False, False, True, False): "FF_TF", (True, False, False, False): "TF_FF", (False, False, False, False): "FF_FF"}
+
+
+@pytest.mark.parametrize("key", sorted(_VARIANTS), ids=lambda k: _VARIANTS[k])
+def test_loader_all_eight_create_data_variants_match_the_reference(key):
+    """Every `_create_data_from_toks_*` of train_gpt.py:686-764, run as it stands (AST-extracted, oracle/gen_golden.py) on the same
+    rank slices: inputs from the left-padded table pulled from the left, targets from the right-padded table pulled from the right,
+    shifted by one token / bpt byte slots; a None of the reference is a None here (bit-exact otherwise)."""
+    from mixture_of_tokenizers_amd import loader
+    from mixture_of_tokenizers_amd.modules import ByteHyperparameters
+    z = np.load(G / "loader.npz")
+    bpt, vocab = 16, 512
+    tabl, tabr = dev(gi.synth_ttb(3001, vocab, bpt, "left")), dev(gi.synth_ttb(3001, vocab, bpt, "right"))
+    byte_in, pull_in, byte_out, pull_out = key
+    bp = ByteHyperparameters(bytes_per_token=bpt, byte_mixin_method="concat" if byte_in else "noop", pull_in=pull_in,
+                             byte_mixout_method="copy" if byte_out else "noop", pull_out=pull_out, padding_in="left", padding_out="right")
+    create = loader.make_create_data_from_toks(bp, tabl, tabr)
+    data = torch.from_numpy(z["data"])
+    pos, batch, seq = int(z["pos"]), int(z["batch"]), int(z["seq"])
+    name = _VARIANTS[key]
+    assert name in set(z["variants/names"])
+    for world, rank in ((1, 0), (2, 1)):
+        toks = loader.rank_slice(data, pos, batch, seq, rank, world).to(DEV)
+        got = dict(zip(("toks_in", "bytes_padded_in", "bytes_pulled_in", "targets"), create(toks)))
+        for what, val in got.items():
+            k = f"variants/w{world}r{rank}/{name}/{what}"
+            if k not in z.files:
+                assert val is None, (name, what)
+            else:
+                assert val is not None and val.is_contiguous(), (name, what)
+                np.testing.assert_array_equal(host(val), z[k])
+                assert val.dtype == (torch.int32 if what == "toks_in" or (what == "targets" and not byte_out) else torch.int64)
+    with pytest.raises(KeyError):      # a combination outside the reference's dispatch table is a KeyError there too (766-783)
+        loader.make_create_data_from_toks(ByteHyperparameters(bytes_per_token=bpt, byte_mixin_method="noop", pull_in=True, byte_mixout_method="noop",
+                                                              pull_out=True), tabl, tabr)
+
+
 def test_distributed_data_generator_end_to_end(tmp_path, monkeypatch):
     """Shards on disk -> generator (train_gpt.py:651-806) -> tensors on the GPU, both ranks of a
     2-way batch shard, checked against the oracle run on the same token stream."""

@@ -93,3 +93,36 @@ def test_char_mixer_modules(mot):
         blk.mix(fe.embed_tokens(dev(toks)), fe.char_embeddings(dev(bad)))
     with pytest.raises(IndexError):
         mot.check_status()
+
+
+def test_char_swa_across_slabs(mot):
+    """More tokens than one 65 536-token slab of the launcher: B x T = 3 x 30 000, so the second slab starts in the
+    middle of batch row 2 and a window reads across the slab boundary.  The whole output is too big for the numpy oracle; the
+    rows around every slab and batch-row boundary are checked instead: a stretch of a batch row, run as its own one-row input,
+    must give the same values (a window never leaves its row and the kernel applies no position-dependent rotation), and that
+    stretch is held to the float64 oracle."""
+    B, T, c_v, d, H, hd, window = 3, 30000, 8, 128, 2, 64, 8
+    Vt, Vc = 700, 132
+    c = case(11, B, T, c_v, d, H, hd, Vt, Vc)
+    g = {k: dev(v) for k, v in c.items()}
+    lt, lc = torch.tensor([0.8], device=DEV), torch.tensor([1.3], device=DEV)
+    kw = dict(attn_norm_w=g["wa"], char_norm_w=g["wc"], wq=g["wq"], wk=g["wk"], wv=g["wv"], wo=g["wo"], n_heads=H, head_dim=hd, window=window,
+              norm_eps=1e-5, version="two_residual", lambda_tok=lt, lambda_char=lc)
+    x = mot.functional.char_swa(g["toks"], g["cid"], g["Et"], g["Ec"], **kw)
+    mot.check_status()
+    assert x.shape == (B, T, d)
+    xf = host(x)
+    slab = 65536
+    cut = slab - 2 * T                                   # position inside batch row 2 where the second slab starts
+    assert 0 < cut < T
+    for row, lo, hi in ((2, cut - 200, cut + 200), (0, 0, 300), (1, T - 300, T), (2, T - 300, T)):
+        sub_t, sub_c = g["toks"][row:row + 1, lo:hi].contiguous(), g["cid"][row:row + 1, lo:hi].contiguous()
+        xs = host(mot.functional.char_swa(sub_t, sub_c, g["Et"], g["Ec"], **kw))[0]
+        skip = 0 if lo == 0 else window - 1              # the stretch's first window - 1 tokens lack their left context
+        a, b_ = xf[row, lo + skip:hi], xs[skip:]
+        assert np.abs(a - b_).max() <= 1e-6 * np.abs(b_).max(), (row, lo, hi, np.abs(a - b_).max())
+        ref = orc.char_swa(c["toks"][row:row + 1, lo:hi], c["cid"][row:row + 1, lo:hi], c["Et"], c["Ec"], c["wa"], c["wc"], c["wq"], c["wk"],
+                           c["wv"], c["wo"], n_heads=H, head_dim=hd, window=window, norm_eps=1e-5, version="two_residual",
+                           lambda_tok=0.8, lambda_char=1.3)[0]
+        err = np.abs(xs[skip:].astype(np.float64) - ref[skip:]).max()
+        assert err <= 5e-6 * np.abs(ref).max(), (row, lo, hi, err)

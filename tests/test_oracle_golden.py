@@ -108,6 +108,35 @@ def test_loader_slice_shift_and_create_batch():
     np.testing.assert_array_equal(full, z["create_batch/full"])
 
 
+def test_loader_all_eight_variants_from_the_oracle():
+    """The oracle's index functions composed as each `_create_data_from_toks_*` composes the reference's (train_gpt.py:686-764),
+    against the reference's own outputs: which views exist, which table / pull direction feeds them, the one-token / bpt-slot shift."""
+    z = np.load(G / "loader.npz")
+    bpt, vocab = 16, 512
+    tabl = ttb_f32(gi.synth_ttb(3001, vocab, bpt, "left"))
+    tabr = ttb_f32(gi.synth_ttb(3001, vocab, bpt, "right"))
+    pos, batch, seq = int(z["pos"]), int(z["batch"]), int(z["seq"])
+    assert sorted(z["variants/names"]) == ["FF_FF", "FF_TF", "FF_TT", "TF_FF", "TF_TT", "TT_FF", "TT_TF", "TT_TT"]
+    for world, rank in ((1, 0), (2, 1)):
+        toks_in, tgt = orc.rank_slice_shift(z["data"], pos, batch, seq, rank, world)
+        full = np.concatenate([toks_in, tgt[:, -1:]], axis=1)
+        pin = orc.tokens_to_bytes(full, tabl)
+        pout = orc.tokens_to_bytes(full, tabr)
+        views = {"toks_in": toks_in, "tok_targets": tgt, "padded_in": pin[:, :-bpt], "pulled_in": orc.pull_from_left(pin, bpt, gi.PAD, gi.EOT)[:, :-bpt],
+                 "padded_out": pout[:, bpt:], "pulled_out": orc.pull_from_right(pout, bpt, gi.PAD, gi.EOT)[:, bpt:]}
+        for name in z["variants/names"]:
+            bi, pi, bo, po = (c == "T" for c in name.replace("_", ""))
+            want = {"toks_in": views["toks_in"], "bytes_padded_in": views["padded_in"] if bi else None,
+                    "bytes_pulled_in": views["pulled_in"] if (bi and pi) else None,
+                    "targets": (views["pulled_out"] if po else views["padded_out"]) if bo else views["tok_targets"]}
+            for what, val in want.items():
+                k = f"variants/w{world}r{rank}/{name}/{what}"
+                if val is None:
+                    assert k not in z.files, k
+                else:
+                    np.testing.assert_array_equal(val, z[k], err_msg=k)
+
+
 def test_mathblations_digits_and_mixin():
     z = np.load(G / "mathblations_c1.npz")
     np.testing.assert_array_equal(orc.tokens_to_digits(np.arange(1003), 3).reshape(1003, 3), z["digit_table"])
