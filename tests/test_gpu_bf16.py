@@ -125,23 +125,30 @@ def _near_bf16_boundary(v, rel):
     return (np.abs(frac - 0.5) * step <= rel * av) & (av > 0)
 
 
-def _assert_excused_by_a_rounding_boundary(got, want, far, toks, ids, Et, Eb, bpt, kw):
-    """The noise floor of the concat tests is self-proving: an element that is MORE than two bf16 steps from
-    the oracle but inside the floor is excused only if its token really has a concat-operand element sitting on a bf16 rounding
-    boundary -- within 2^-20 relative, what the kernel's fp32 rms factor (v_rsq / v_rcp, <= 1 ulp each, and its summation order)
-    can move the product by -- and at most 1 % of the tokens may need the excuse.  Anything else is a kernel error."""
-    excused = (ulps(got, want) > 2) & ~far
+def _assert_excused_by_a_rounding_boundary(got, want, far, rs, toks, ids, Et, Eb, bpt, kw):
+    """The noise floor of the concat tests is self-proving.  An element MORE than two bf16 steps from the
+    oracle but inside the floor is excused for one of two reasons, and each is checked:
+      (a) fp32 accumulation order: the contraction sums K <= 1024 products of magnitude <= ~0.1 in fp32 (MFMA chains) where the
+          oracle sums in float64; sqrt(K) * 2^-24 * sum|terms| ~ 2e-5 absolute, times the output rms factor -- only outputs
+          near zero can be many bf16 STEPS off by that little.  Elements within 4e-5 * rs need no further excuse.
+      (b) everything larger must come from a concat-operand element rounded to bf16 the other way: the token must really have an
+          operand element within 2^-20 relative of a bf16 rounding boundary (what the kernel's fp32 rms factor -- v_rsq / v_rcp,
+          <= 1 ulp each, and its summation order -- can move the product by), and at most 1 % of the tokens may need it.
+    Anything else is a kernel error."""
+    diff = np.abs(got.astype(np.float64) - want)
+    excused = (ulps(got, want) > 2) & ~far & (diff > 4e-5 * rs)
     tok_exc = excused.any(-1)
     if not tok_exc.any():
         return
     if not (kw.get("norm_tok") or kw.get("norm_byte")):
-        raise AssertionError("elements beyond 2 bf16 steps although no operand element is computed (no per-embedding norm): nothing can sit on a boundary")
+        raise AssertionError("elements beyond 2 bf16 steps and beyond fp32 accumulation noise although no operand element is computed "
+                             "(no per-embedding norm): nothing can sit on a rounding boundary")
     u = _concat_operand64(toks, ids, Et, Eb, bpt, bool(kw.get("norm_tok")), bool(kw.get("norm_byte")))
     on_boundary = _near_bf16_boundary(u, 2.0 ** -20).any(-1)
     bad = tok_exc & ~on_boundary
-    assert not bad.any(), f"{int(bad.sum())} tokens beyond 2 bf16 steps without an operand element on a rounding boundary, first at {np.argwhere(bad)[0]}"
+    assert not bad.any(), (f"{int(bad.sum())} tokens beyond 2 bf16 steps without an operand element on a rounding boundary, first at "
+                           f"{np.argwhere(bad)[0]}: max |diff| there {diff[bad].max():.3e}")
     assert tok_exc.mean() <= 0.01, f"{tok_exc.mean():.3%} of the tokens need the rounding-boundary excuse"
-
 
 
 # ------------------------------------------------------------------------------------------------
@@ -203,7 +210,7 @@ def test_bf16_concat_linear_vs_oracle(mot, path, Dt, Db, bpt, Dm, Vt, B, T, kw, 
     far = np.abs(got.astype(np.float64) - want) > noise
     assert ulps(got, want)[far].max(initial=0) <= 2
     assert (got == want).mean() > 0.97
-    _assert_excused_by_a_rounding_boundary(got, want, far, toks, pulled, Et, Eb, bpt, kw)
+    _assert_excused_by_a_rounding_boundary(got, want, far, rs, toks, pulled, Et, Eb, bpt, kw)
     # the same with the byte ids given (the module seam)
     xg = mot.embed_mix(dev(toks), b16(Et), b16(Eb), mode="concat_linear", bpt=bpt, ids_a=dev(pulled), weight=b16(W), bias=b16(bias),
                        **sel, **kw)
@@ -211,7 +218,7 @@ def test_bf16_concat_linear_vs_oracle(mot, path, Dt, Db, bpt, Dm, Vt, B, T, kw, 
     farg = np.abs(gotg.astype(np.float64) - want) > noise
     assert ulps(gotg, want)[farg].max(initial=0) <= 2
     assert (gotg == want).mean() > 0.97
-    _assert_excused_by_a_rounding_boundary(gotg, want, farg, toks, pulled, Et, Eb, bpt, kw)
+    _assert_excused_by_a_rounding_boundary(gotg, want, farg, rs, toks, pulled, Et, Eb, bpt, kw)
 
 
 @pytest.mark.parametrize("B,T", [(3, 333), (9, 2003)], ids=["999_tokens", "18027_tokens"])   # 16 / 32 tokens per wave in the index pass
@@ -263,7 +270,8 @@ def test_bf16_concat_full_size_c2(mot):
     noise = np.maximum(5e-4, float(np.abs(W).max()) * 2.0 ** -5 / np.sqrt((y ** 2).mean(-1, keepdims=True) + 2.0 ** -7))   # see the test above
     far = np.abs(got.astype(np.float64) - want) > noise
     assert ulps(got, want)[far].max(initial=0) <= 2 and (got == want).mean() > 0.97
-    _assert_excused_by_a_rounding_boundary(got, want, far, toks[rows], pulled, Et, Eb, bpt, dict(norm_tok=True, norm_byte=True))
+    _assert_excused_by_a_rounding_boundary(got, want, far, 1.0 / np.sqrt((y ** 2).mean(-1, keepdims=True) + 2.0 ** -7), toks[rows], pulled, Et, Eb, bpt,
+                                           dict(norm_tok=True, norm_byte=True))
     x = r.x
     assert bool(torch.isfinite(x.float()).all())
     ms = (x.double() ** 2).mean(-1)
