@@ -230,8 +230,9 @@ typedef struct MotEmbedMixDesc {
  * `fwd` is the forward's descriptor with id_source == MOT_IDS_GIVEN (pass the byte ids the forward
  * returned through out_ids_*); `out`, `out_ids_*`, `counters` are ignored.  Gradients are ACCUMULATED
  * (+=) into the given buffers, so a parameter's .grad can be passed directly; NULL = not wanted.
- * Built: MOT_MIX_SUM, MOT_MIX_NOOP, MOT_MIX_CONCAT_LINEAR, and MOT_MIX_MEAN in fp32 without an output norm (the residual of
- * inference.py:267 has none; its small character table makes the table gradient a dense product, mot_backward.hip).
+ * Built: MOT_MIX_SUM, MOT_MIX_NOOP, MOT_MIX_CONCAT_LINEAR, and MOT_MIX_MEAN without an output norm (the residual of
+ * inference.py:267 has none; its small character table makes the table gradient a dense product, mot_backward.hip; with
+ * bf16 tables that product runs on operands widened slab by slab into the workspace).
  * With dtype == MOT_BF16 the tables, weight/bias, `out` and grad_out are bf16 as in the forward, while
  * every gradient buffer below stays FP32 (sums of thousands of terms are accumulated in fp32; the
  * caller rounds once when it needs a bf16 .grad, train_gpt.py:1124-1126).

@@ -2471,7 +2471,7 @@ __global__ __launch_bounds__(kThreads) void mean_finalize_kernel(const float *__
 }
 
 constexpr int64_t kMeanSlab = 65536;
-struct MeanBwdLayout { size_t rn, vn, m1, w, cnt, s, scatter, total; int ld; };
+struct MeanBwdLayout { size_t rn, vn, m1, w, cnt, s, scatter, tab32, g32, total; int ld; };
 static MeanBwdLayout mean_bwd_layout(const MotEmbedMixDesc &d) {
     MeanBwdLayout L;
     const int64_t N = d.n_rows * d.tokens_per_row, slab = N < kMeanSlab ? N : kMeanSlab;
@@ -2479,7 +2479,11 @@ static MeanBwdLayout mean_bwd_layout(const MotEmbedMixDesc &d) {
     size_t o = 0;
     auto take = [&](size_t n) { size_t at = o; o += (n + 63) & ~(size_t)63; return at; };
     L.rn = take(d.byte_rows); L.vn = take((size_t)d.byte_rows * d.byte_dim); L.m1 = take((size_t)d.byte_rows * d.byte_dim); L.w = take(d.byte_rows);
-    L.cnt = take((size_t)slab * L.ld); L.s = take((size_t)slab * L.ld); L.scatter = take(scatter_ws_ints(d)); L.total = o;
+    L.cnt = take((size_t)slab * L.ld); L.s = take((size_t)slab * L.ld); L.scatter = take(scatter_ws_ints(d));
+    // bf16 tables / gradient rows: the character side runs on fp32 copies -- the 132-row table once, the gradient rows a slab at a time
+    L.tab32 = L.g32 = 0;
+    if (d.dtype == MOT_BF16) { L.tab32 = take((size_t)d.byte_rows * d.byte_dim); L.g32 = take((size_t)slab * d.byte_dim); }
+    L.total = o;
     return L;
 }
 
@@ -2488,7 +2492,9 @@ __global__ __launch_bounds__(kThreads) void scale_rows_kernel(const float *__res
 }
 
 static int launch_embed_mix_bwd_mean(const MotEmbedMixDesc &d, const MotEmbedMixGrads &gr, hipStream_t stream) {
-    if (d.dtype != MOT_F32) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: the MEAN mode's backward is built for fp32 tables");
+    // bf16 (round 3): the token side reads bf16 rows natively (the NOOP scatter kernel); the character side -- dense products over
+    // the token axis on the fp32 MFMA -- runs on operands widened once (the table) or slab by slab (the gradient rows); sums fp32.
+    const bool bf = d.dtype == MOT_BF16;
     if (d.norm_out) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: MEAN with an output norm has no backward (the reference's residual, inference.py:267, has none)");
     if (d.id_source != MOT_IDS_GIVEN || d.ids_b) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd MEAN: one given id tensor");
     if (d.byte_rows > 1024) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd MEAN: %lld character rows (> 1024): the dense formulation is for small tables", (long long)d.byte_rows);
@@ -2498,7 +2504,7 @@ static int launch_embed_mix_bwd_mean(const MotEmbedMixDesc &d, const MotEmbedMix
     float *ws = (float *)d.workspace;
     const int64_t N = d.n_rows * d.tokens_per_row, slab = N < kMeanSlab ? N : kMeanSlab;
     const int rows = (int)d.byte_rows, D = d.byte_dim;
-    const float eps = d.eps > 0.f ? d.eps : FLT_EPSILON;
+    const float eps = d.eps > 0.f ? d.eps : (d.dtype == MOT_BF16 ? kBf16Eps : FLT_EPSILON);   // F.rms_norm(eps=None): finfo of the input dtype
     int rc;
     // ---- token side: x = s_t * norm?(E_t[tok]) + (...) is the tokens-only mix as far as the token table and s_t are concerned
     {
@@ -2511,11 +2517,16 @@ static int launch_embed_mix_bwd_mean(const MotEmbedMixDesc &d, const MotEmbedMix
         if ((rc = run_scatter<MOT_MIX_NOOP>(A, t, (int32_t *)(ws + L.scatter), nullptr, stream))) return rc;
     }
     // ---- character side
-    const float *V = (const float *)d.byte_table, *rn = nullptr;
+    const float *tab = (const float *)d.byte_table;
+    if (bf) {
+        if ((rc = launch_widen(d.byte_table, (size_t)rows * D, ws + L.tab32, stream))) return rc;
+        tab = ws + L.tab32;
+    }
+    const float *V = tab, *rn = nullptr;
     const bool need_s = d.norm_byte || gr.d_scale_byte;
     if (d.norm_byte) {
-        if ((rc = launch_rows_rnorm(d.byte_table, rows, D, eps, ws + L.rn, MOT_F32, stream))) return rc;
-        hipLaunchKernelGGL(scale_rows_kernel, dim3(256), dim3(kThreads), 0, stream, (const float *)d.byte_table, ws + L.rn, rows, D, ws + L.vn);
+        if ((rc = launch_rows_rnorm(tab, rows, D, eps, ws + L.rn, MOT_F32, stream))) return rc;
+        hipLaunchKernelGGL(scale_rows_kernel, dim3(256), dim3(kThreads), 0, stream, tab, ws + L.rn, rows, D, ws + L.vn);
         V = ws + L.vn; rn = ws + L.rn;
     }
     if ((rc = launch_zero_words(ws + L.m1, (int64_t)rows * D, stream))) return rc;
@@ -2523,6 +2534,10 @@ static int launch_embed_mix_bwd_mean(const MotEmbedMixDesc &d, const MotEmbedMix
     for (int64_t n0 = 0; n0 < N; n0 += slab) {
         const int64_t nn = N - n0 < slab ? N - n0 : slab;
         const float *G = (const float *)gr.grad_out + n0 * D;
+        if (bf) {
+            if ((rc = launch_widen((const __bf16 *)gr.grad_out + n0 * D, (size_t)nn * D, ws + L.g32, stream))) return rc;
+            G = ws + L.g32;
+        }
         hipLaunchKernelGGL(mean_counts_kernel, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.ids_a + n0 * d.bpt, nn, d.bpt, rows,
                            L.ld, ws + L.cnt, d.status);
         if ((rc = check_launch("mean_counts_kernel"))) return rc;
@@ -2535,7 +2550,7 @@ static int launch_embed_mix_bwd_mean(const MotEmbedMixDesc &d, const MotEmbedMix
             if ((rc = check_launch("mean_colsum_kernel"))) return rc;
         }
     }
-    hipLaunchKernelGGL(mean_finalize_kernel, dim3(256), dim3(kThreads), 0, stream, ws + L.m1, (const float *)d.byte_table, rn, ws + L.w, rows, D, d.bpt,
+    hipLaunchKernelGGL(mean_finalize_kernel, dim3(256), dim3(kThreads), 0, stream, ws + L.m1, tab, rn, ws + L.w, rows, D, d.bpt,
                        d.scale_byte, (float *)gr.d_byte_table, gr.d_scale_byte);
     return check_launch("mean_finalize_kernel");
 }

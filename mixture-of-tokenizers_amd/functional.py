@@ -556,7 +556,7 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
               scale_tok: torch.Tensor | None = None, scale_byte: torch.Tensor | None = None, **kw):
     """The fused front-end (see `_embed_mix_fwd` for the arguments).  With autograd enabled and
     differentiable parameters it records one backward node: modes "sum", "noop", "concat_linear" with
-    float32 or bfloat16 tables; "mean" with float32 tables and no output norm.  Anything else raises here,
+    float32 or bfloat16 tables; "mean" without an output norm.  Anything else raises here,
     at forward time, rather than in backward()."""
     params = (tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"))
     if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
@@ -564,10 +564,10 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
             raise RuntimeError(
                 f"mixture-of-tokenizers_amd: backward of mode '{kw['mode']}' is not built yet (forward only); "
                 "call it under torch.no_grad() or with frozen parameters")
-        if kw["mode"] == "mean" and (tok_table.dtype != torch.float32 or kw.get("norm_out")):
+        if kw["mode"] == "mean" and kw.get("norm_out"):
             raise RuntimeError(
-                "mixture-of-tokenizers_amd: the backward of the MEAN mix is built for float32 tables without an output norm "
-                "(mot_embed_mix_bwd, include/mot.h); call it under torch.no_grad() or with frozen parameters")
+                "mixture-of-tokenizers_amd: the backward of the MEAN mix is built without an output norm (the reference's residual, "
+                "inference.py:267, has none; mot_embed_mix_bwd, include/mot.h); call it under torch.no_grad() or with frozen parameters")
         if kw.get("out") is not None or kw.get("counters") is not None:
             raise ValueError("out= / counters= cannot be combined with autograd")
         r = _EmbedMixFn.apply(tok_table, byte_table, scale_tok, scale_byte, kw.get("weight"), kw.get("bias"), tokens, kw)
@@ -734,8 +734,8 @@ def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tens
              n_heads: int, head_dim: int, window: int = 8, norm_eps: float = 1e-5, version: str = "two_residual",
              lambda_tok: torch.Tensor | None = None, lambda_char: torch.Tensor | None = None) -> torch.Tensor:
     """The Llama character mixer up to the feed-forward (inference.py:146-224 + 260-267 on the gathers of 323-327):
-    tokens (B, T) int, char_ids (B, T, c_v) int64 -> h (B, T, dim) fp32.  Forward only (the file is the reference's inference
-    path); see mot_char_swa_fwd in include/mot.h."""
+    tokens (B, T) int, char_ids (B, T, c_v) int64 -> h (B, T, dim) fp32 (bf16 when the tables are bf16: operands widened once, fp32
+    arithmetic, one rounding).  Forward only (the file is the reference's inference path); see mot_char_swa_fwd in include/mot.h."""
     if tokens.ndim == 1:
         tokens, char_ids = tokens[None], char_ids[None]
     if char_ids.ndim != 3 or char_ids.shape[:2] != tokens.shape:
@@ -749,6 +749,15 @@ def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tens
     tok = _contig(tokens.to(torch.int32), torch.int32, "tokens")
     cid = _contig(char_ids, torch.int64, "char_ids")
     B, T = tok.shape
+    # bfloat16 tables / weights (round 3; the reference script itself runs in the default float32): every operand is widened once
+    # per call -- the values a bf16 model holds -- the arithmetic is the fp32 kernels', and the result is rounded once to bf16
+    bf = tok_table.dtype == torch.bfloat16
+    if bf:
+        if char_table.dtype != torch.bfloat16:
+            raise TypeError(f"char_swa: char_table is {char_table.dtype} but the token table is bfloat16")
+        widen = lambda t: None if t is None else t.detach().to(torch.bfloat16).float()
+        tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, lambda_tok, lambda_char = (
+            widen(t) for t in (tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, lambda_tok, lambda_char))
     tt, ct = _contig(tok_table.detach(), f32, "tok_table"), _contig(char_table.detach(), f32, "char_table")
     D, hdim = tt.shape[1], n_heads * head_dim
     if ct.shape[1] != D:
@@ -775,4 +784,4 @@ def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tens
         d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()
     capi.check(capi.lib.mot_char_swa_fwd(C.byref(d), capi.stream_of(dev)))
     capi.after_call(dev)
-    return out
+    return out.to(torch.bfloat16) if bf else out

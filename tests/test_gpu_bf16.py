@@ -376,6 +376,48 @@ def test_bf16_sum_backward_vs_oracle(mot, D, Db, bpt, Vt, B, T, kw, seed):
         assert abs(float(got["scale_byte"]) - ref["scales"][1]) < 2e-5 * abs(ref["scales"]).max()
 
 
+@pytest.mark.parametrize("D,bpt,Vt,Vc,B,T,kw,seed", [
+    (2048, 8, 3000, 132, 2, 300, dict(scaled=True), 9851),                        # config-5 dims: the two_residual mix with its lambdas
+    (256, 8, 500, 132, 3, 171, dict(norm_byte=True, scaled=True), 9852),          # per-character norm
+    (512, 5, 700, 132, 1, 70001, dict(), 9853),                                   # more than one 65 536-token slab of the character side
+])
+def test_bf16_mean_backward_vs_oracle(mot, D, bpt, Vt, Vc, B, T, kw, seed):
+    """Backward of the MEAN mix with bf16 tables and gradient rows (round 3: the token side reads bf16 natively, the character side's
+    dense products run on operands widened slab by slab; sums in fp32).  Same bar as the bf16 SUM backward: 2e-5 of each gradient's
+    maximum against the float64 oracle evaluated on the bf16 values.  Parity unpinned by the reference (inference.py never trains)."""
+    kw = dict(kw)
+    scaled = kw.pop("scaled", False)
+    rs = np.random.RandomState(seed)
+    toks = rs.randint(0, Vt, (B, T)).astype(np.int32)
+    ids = rs.randint(0, Vc, (B, T * bpt)).astype(np.int64)
+    Et, Ec = orc.bf16_round(gi.normal_table(seed + 1, Vt, D)), orc.bf16_round(gi.normal_table(seed + 2, Vc, D))
+    g = orc.bf16_round(rs.standard_normal((B, T, D)))
+    okw, gkw = dict(kw), dict(kw)
+    if scaled:
+        okw.update(scale_tok=0.8, scale_byte=1.3)
+        gkw.update(scale_tok=torch.tensor([0.8], device=DEV), scale_byte=torch.tensor([1.3], device=DEV))
+    orc.set_eps(2.0 ** -7)
+    try:
+        ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Ec.astype(np.float64), g.astype(np.float64), mode="mean", bpt=bpt,
+                                dtype=np.float64, **okw)
+    finally:
+        orc.set_eps(0.0)
+    got = mot.functional.embed_mix_backward(dev(g).bfloat16(), dev(toks), dev(Et).bfloat16(), dev(Ec).bfloat16(), mode="mean", bpt=bpt,
+                                            ids_a=dev(ids), **gkw)
+    mot.check_status()
+    assert got["tok_table"].dtype == torch.float32 and got["byte_table"].dtype == torch.float32
+    assert relmax(host(got["tok_table"]), ref["tok_table"]) < 2e-5
+    assert relmax(host(got["byte_table"]), ref["byte_table"]) < 2e-5
+    if scaled:
+        assert abs(float(got["scale_tok"]) - ref["scales"][0]) < 2e-5 * max(abs(ref["scales"]).max(), np.sqrt(B * T * D))
+        assert abs(float(got["scale_byte"]) - ref["scales"][1]) < 2e-5 * max(abs(ref["scales"]).max(), np.sqrt(B * T * D))
+    # and through autograd: bf16 parameters get bf16 .grad (rounded once from the fp32 sums)
+    pt, pc = torch.nn.Parameter(dev(Et).bfloat16()), torch.nn.Parameter(dev(Ec).bfloat16())
+    x = mot.embed_mix(dev(toks), pt, pc, mode="mean", bpt=bpt, ids_a=dev(ids), **gkw)
+    x.backward(dev(g).bfloat16())
+    assert pt.grad.dtype == torch.bfloat16 and torch.equal(pt.grad, got["tok_table"].to(torch.bfloat16))
+
+
 @pytest.mark.parametrize("Dt,Db,bpt,Dm,Vt,B,T,kw,seed", [
     (256, 32, 16, 768, 4096, 2, 512, dict(norm_tok=True, norm_byte=True, norm_out=True), 9801),     # C2-CONCAT dims
     (256, 256, 3, 256, 1003, 8, 32, dict(bias=True, bytes_first=True), 9802),                       # mathblations dims

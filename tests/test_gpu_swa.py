@@ -126,3 +126,22 @@ def test_char_swa_across_slabs(mot):
                            lambda_tok=0.8, lambda_char=1.3)[0]
         err = np.abs(xs[skip:].astype(np.float64) - ref[skip:]).max()
         assert err <= 5e-6 * np.abs(ref).max(), (row, lo, hi, err)
+
+
+def test_char_swa_bf16_tables(mot):
+    """bf16 tables and weights: operands widened once, fp32 arithmetic, one rounding of the result -- held to the float64 oracle
+    evaluated on the bf16 VALUES, within one bf16 step (parity unpinned, as everything of this file)."""
+    B, T, c_v, d, H, hd, window = 2, 60, 8, 256, 4, 64, 8
+    c = case(21, B, T, c_v, d, H, hd, 700, 132)
+    c16 = {k: (orc.bf16_round(v) if v.dtype == np.float32 else v) for k, v in c.items()}
+    lt, lc = float(orc.bf16_round(np.float32(0.8))), float(orc.bf16_round(np.float32(1.3)))
+    ref = orc.char_swa(c16["toks"], c16["cid"], c16["Et"], c16["Ec"], c16["wa"], c16["wc"], c16["wq"], c16["wk"], c16["wv"], c16["wo"], n_heads=H,
+                       head_dim=hd, window=window, norm_eps=1e-5, version="two_residual", lambda_tok=lt, lambda_char=lc)
+    b16 = lambda a: dev(a).bfloat16()
+    x = mot.functional.char_swa(dev(c["toks"]), dev(c["cid"]), b16(c16["Et"]), b16(c16["Ec"]), attn_norm_w=b16(c16["wa"]), char_norm_w=b16(c16["wc"]),
+                                wq=b16(c16["wq"]), wk=b16(c16["wk"]), wv=b16(c16["wv"]), wo=b16(c16["wo"]), n_heads=H, head_dim=hd, window=window,
+                                norm_eps=1e-5, version="two_residual", lambda_tok=torch.tensor([0.8], device=DEV).bfloat16(),
+                                lambda_char=torch.tensor([1.3], device=DEV).bfloat16())
+    assert x.dtype == torch.bfloat16 and x.shape == (B, T, d)
+    got, want = host(x.float()).astype(np.float64), ref
+    assert (np.abs(got - want) <= 2.0 ** -8 * np.maximum(np.abs(want), 2.0 ** -6)).all()      # one bf16 step (2^-8 relative), floor near zero
