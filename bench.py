@@ -596,7 +596,7 @@ def main(argv=None):
             fms = timed_launches(plan, nb, warm=3)
             foms = timed_launches(fwd_and_order, nb, warm=3)
             read_bytes = 2 * out.element_size() * D * tokens_per_step   # grad_out row + token row per position (byte rows and ids come from L2)
-            kname = "embed_mix_bwd_plain_kernel" if args.dtype == "f32" else "embed_mix_bwd_full_kernel"
+            kname = "embed_mix_bwd_plain_kernel"
             res["backward"] = {"kernel": kname, "kernel_ms": bms, "tokens_per_s": tokens_per_step / (bms * 1e-3),
                                "hbm_read_GBps": read_bytes / (bms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS,
                                "token_order_ms": oms, "backward_grouping_itself_ms": sms,

@@ -1097,7 +1097,9 @@ static int dispatch_ne_lc(const BwdArgs &A, size_t lds, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------
 constexpr int kPlThreads = 768, kPlWaves = kPlThreads / 64;   // 12 waves, 3 per SIMD: 168 registers per lane
 
-template <int MODE, int NE, bool NORM_OUT>
+// T: element type of the tables and of grad_out (float, or __bf16 as the production loop runs them, train_gpt.py:1124-1126); all
+// arithmetic and every gradient buffer are fp32.  A lane's chunk is FOUR elements either way (16 bytes of fp32, 8 bytes of bf16).
+template <int MODE, int NE, bool NORM_OUT, typename T>
 __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const BwdArgs A) {
 #pragma clang fp contract(fast)
     constexpr int D = 64 * NE, NV = NE / 4;
@@ -1125,14 +1127,16 @@ __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const B
     int sl[NV], wo[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) { const int c = lane + 64 * v; sl[v] = BYTES ? c / cps : 0; wo[v] = BYTES ? 4 * (c - sl[v] * cps) : 0; }
-    const uint32_t lane_off = (uint32_t)lane * 16u;
-    auto load_row = [&](float4v (&dst)[NV], const void *rbase) {
+    constexpr uint32_t kChunk = 4u * (uint32_t)sizeof(T);          // bytes of a lane's chunk in the tables / grad_out
+    const uint32_t lane_off = (uint32_t)lane * kChunk;
+    const T *tok_table = (const T *)A.tok_table, *byte_table = (const T *)A.byte_table, *grad_out = (const T *)A.grad_out;
+    auto load_row = [&](float4v (&dst)[NV], const T *rbase) {     // one row of D elements in chunk order, widened
 #pragma unroll
-        for (int v = 0; v < NV; ++v) dst[v] = *(const float4v *)((const char *)rbase + (lane_off + 1024u * v));
+        for (int v = 0; v < NV; ++v) dst[v] = Elem<T>::load4((const T *)((const char *)rbase + (lane_off + 64u * kChunk * v)));
     };
     auto load_byte_rows = [&](float4v (&dst)[NV], const int (&id)[NV]) {
 #pragma unroll
-        for (int v = 0; v < NV; ++v) dst[v] = *(const float4v *)(A.byte_table + (int64_t)id[v] * A.Db + wo[v]);
+        for (int v = 0; v < NV; ++v) dst[v] = Elem<T>::load4(byte_table + (int64_t)id[v] * A.Db + wo[v]);
     };
     auto byte_slot = [&](int id) { return id < A.priv_lo ? id : (id >= A.priv_hi0 ? id - A.priv_hi0 + A.priv_lo : -1); };
     // The bpt ids of a position are one cache line: lane k < bpt loads id k (one 8-byte load per position), range-checks it, and
@@ -1161,7 +1165,7 @@ __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const B
         float gmax = 0.f;
         if (s_begin < s_end) {
             float4v gs[NV];
-            load_row(gs, A.grad_out + (int64_t)A.pos_sorted[s_begin] * D);
+            load_row(gs, grad_out + (int64_t)A.pos_sorted[s_begin] * D);
 #pragma unroll
             for (int v = 0; v < NV; ++v) gmax = fmaxf(fmaxf(gmax, fmaxf(fabsf(gs[v].x), fabsf(gs[v].y))), fmaxf(fabsf(gs[v].z), fabsf(gs[v].w)));
             gmax = wave_max(gmax);
@@ -1201,7 +1205,7 @@ __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const B
     auto new_run = [&](int tok) {                                 // the finished row leaves, this token's row comes into the strip, an empty sum
         flush();
         cur = tok;
-        load_row(acc, A.tok_table + (int64_t)tok * D);
+        load_row(acc, tok_table + (int64_t)tok * D);
         __builtin_amdgcn_s_waitcnt(0x0f70);                        // vmcnt(0) (gfx9 encoding: vmcnt [3:0] + [15:14]; expcnt, lgkmcnt left alone)
         strip_write(acc, 1.0f);
         seg_sync();
@@ -1215,7 +1219,7 @@ __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const B
         if (64 + lane < len) { vpos_hi = A.pos_sorted[seg0 + 64 + lane]; vtok_hi = A.tok_sorted[seg0 + 64 + lane]; }
         auto pos_at = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(vpos, i) : __builtin_amdgcn_readlane(vpos_hi, i - 64); };
         auto tok_at = [&](int i) { return i < 64 ? __builtin_amdgcn_readlane(vtok, i) : __builtin_amdgcn_readlane(vtok_hi, i - 64); };
-        auto g_row = [&](int i) { return (const void *)(A.grad_out + (int64_t)pos_at(min(i, len - 1)) * D); };
+        auto g_row = [&](int i) { return grad_out + (int64_t)pos_at(min(i, len - 1)) * D; };
         float4v b_nx[NV], G0[NV], G1[NV];
         int id_cur[NV], idv_n1 = 0;                               // this place's ids per slot of the lane; the next place's, one per lane
         int64_t idraw_n1 = 0;
@@ -1317,7 +1321,7 @@ __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const B
                             }
                         }
                         seg_sync();
-                        load_row(y, A.tok_table + (int64_t)cur * D);
+                        load_row(y, tok_table + (int64_t)cur * D);
                         __builtin_amdgcn_s_waitcnt(0x0f70);
                         strip_write(y, 1.0f);
                         seg_sync();
@@ -1349,30 +1353,36 @@ __global__ __launch_bounds__(kPlThreads) void embed_mix_bwd_plain_kernel(const B
 #undef PL_ABL
 }
 
-// the configuration this kernel is for: lc_layout's shapes, one id tensor, no per-embedding norm, no learned scalars
+// the configuration this kernel is for: SUM / NOOP over full rows of 256, 512 or 768 columns (D = 64 NE, a lane's chunks are four
+// elements), one id tensor, no per-embedding norm, no learned scalars; fp32 or bf16 tables and gradient rows
 template <int MODE>
 static bool plain_layout(const BwdArgs &A) {
+    if ((A.D & 255) || A.D > 768 || A.Dt != A.D || A.tok_lo != 0) return false;
+    if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D)) return false;
     if (A.norm_tok || A.norm_byte || A.scale_tok || A.scale_byte || A.d_scale_tok || A.d_scale_byte || A.ids_b) return false;
-    if (MODE == MOT_MIX_SUM && ((A.Db & 3) || A.Db > 128)) return false;   // a 16-byte chunk of a row lies inside one byte slot; wide byte rows
+    if (MODE == MOT_MIX_SUM && ((A.Db & 3) || A.Db > 128)) return false;   // a chunk of a row lies inside one byte slot; wide byte rows
                                                                             // (the D-wide "slot" of the cross-attention mixin's two-id backward) do
                                                                             // not fit LDS, and this kernel's path for rows without an LDS slot is slow
-    const int ne = A.D / 64;
-    return ne == 4 || ne == 8 || ne == 12;   // 16 and up: seven row buffers no longer fit 128 registers
+    return true;
 }
 
-template <int MODE, int NE, bool NORM_OUT>
+template <int MODE, int NE, bool NORM_OUT, typename T>
 static int launch_bwd_plain_t(const BwdArgs &A, size_t lds, hipStream_t stream) {
     static std::atomic<uint64_t> lds_ok{0};   // per-device bits
-    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_plain_kernel<MODE, NE, NORM_OUT>, lds_ok, "embed_mix_bwd_plain_kernel")) return rc_lds;
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_plain_kernel<MODE, NE, NORM_OUT, T>, lds_ok, "embed_mix_bwd_plain_kernel")) return rc_lds;
     int64_t blocks = (A.n_tokens + 16 * kPlWaves - 1) / (16 * kPlWaves);   // >= 16 sorted positions per wave
     if (blocks > 256) blocks = 256;   // one workgroup per CU
-    hipLaunchKernelGGL((embed_mix_bwd_plain_kernel<MODE, NE, NORM_OUT>), dim3((unsigned)blocks), dim3(kPlThreads), lds, stream, A);
+    hipLaunchKernelGGL((embed_mix_bwd_plain_kernel<MODE, NE, NORM_OUT, T>), dim3((unsigned)blocks), dim3(kPlThreads), lds, stream, A);
     return check_launch("embed_mix_bwd_plain_kernel");
 }
 template <int MODE, int NE>
 static int launch_bwd_plain(const BwdArgs &A, size_t lds, hipStream_t stream) {
-    if (A.norm_out) return launch_bwd_plain_t<MODE, NE, true>(A, lds, stream);
-    return launch_bwd_plain_t<MODE, NE, false>(A, lds, stream);
+    if (A.in_bf16) {
+        if (A.norm_out) return launch_bwd_plain_t<MODE, NE, true, __bf16>(A, lds, stream);
+        return launch_bwd_plain_t<MODE, NE, false, __bf16>(A, lds, stream);
+    }
+    if (A.norm_out) return launch_bwd_plain_t<MODE, NE, true, float>(A, lds, stream);
+    return launch_bwd_plain_t<MODE, NE, false, float>(A, lds, stream);
 }
 
 template <int MODE>
@@ -1620,7 +1630,8 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
     bool lc = false, plain = false;
     if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
         lc = lc_layout<MODE>(A) && !(A.abl & 8);   // abl 8: dev switch back to the strided kernels
-        plain = lc && plain_layout<MODE>(A) && !(A.abl & 16);   // abl 16: dev switch back to the general lane-contiguous kernel
+        plain = plain_layout<MODE>(A) && !(A.abl & 24);   // abl 16: dev switch back to the general kernels
+        lc = lc || plain;                           // (LDS layout below: one fp32 row per wave, byte-table rows padded by one sum)
     }
     // LDS besides the privatised byte-table sums: per-wave per-slot accumulators (strided kernels) or per-wave transposition rows (lane-contiguous)
     size_t lds = lc ? (size_t)(plain ? kPlWaves : kLcWaves) * A.D * sizeof(float) + 16 : 2 * (size_t)kBwdWaves * kMaxBpt * sizeof(float) + 16;
