@@ -631,3 +631,79 @@ def test_autograd_reuses_the_token_order_per_token_tensor(mot):
     run(toks_b)
     assert F._token_orders.entries[0][3] is not first
     mot.check_status()
+
+
+# ---- embed_mix_bwd_plain_kernel (round 3): its own matrix -- every built row width, both modes, with and without the output norm,
+#      fp32 and bf16, the corner cases of its segment / run / stretch logic, and its slow path (byte ids without an LDS row)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("D,Db,bpt,mode,norm_out,B,T,Vt,seed", [
+    (256, 32, 8, "sum", True, 3, 333, 700, 9601),
+    (512, 32, 16, "sum", False, 2, 500, 300, 9602),
+    (768, 48, 16, "sum", True, 1, 4097, 50, 9603),        # few distinct tokens: long runs across wave stretches and 128-place segments
+    (768, 128, 6, "sum", True, 2, 300, 600, 9604),        # byte rows of 128 columns: only a third of the table has an LDS row -> the slow path
+    (256, 4, 64, "sum", True, 2, 130, 100, 9605),         # one 16-byte chunk per byte slot, 64 slots
+    (768, 48, 16, "sum", True, 1, 5, 9, 9606),            # fewer positions than waves
+    (512, 0, 0, "noop", True, 3, 400, 500, 9607),
+    (768, 0, 0, "noop", False, 2, 777, 64, 9608),
+    (256, 0, 0, "noop", False, 1, 1, 3, 9609),            # one position
+])
+def test_plain_backward_kernel_matrix(mot, dtype, D, Db, bpt, mode, norm_out, B, T, Vt, seed):
+    rs = np.random.RandomState(seed)
+    bf = dtype == "bf16"
+    if bf and Db % 8:
+        pytest.skip("bf16 table rows are multiples of 16 bytes (validated at the boundary)")
+    rnd = (lambda a: orc.bf16_round(a)) if bf else f32
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.0)
+    Et = rnd(gi.normal_table(seed + 2, Vt, D))
+    g = rnd(rs.standard_normal((B, T, D)))
+    cast = (lambda a: dev(a).bfloat16()) if bf else dev
+    kw = dict(norm_out=norm_out)
+    if bf:
+        orc.set_eps(2.0 ** -7)
+    try:
+        if mode == "sum":
+            Eb = rnd(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+            ids = rs.randint(0, gi.BYTE_VOCAB, (B, T * bpt)).astype(np.int64)
+            ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt,
+                                    dtype=np.float64, **kw)
+            got = mot.functional.embed_mix_backward(cast(g), dev(toks), cast(Et), cast(Eb), mode="sum", bpt=bpt, ids_a=dev(ids), **kw)
+            assert rel(host(got["byte_table"]), ref["byte_table"]) < TOL
+        else:
+            ref = orc.embed_mix_bwd(toks, None, None, Et.astype(np.float64), None, g.astype(np.float64), mode="noop", bpt=0, dtype=np.float64, **kw)
+            got = mot.functional.embed_mix_backward(cast(g), dev(toks), cast(Et), mode="noop", **kw)
+    finally:
+        orc.set_eps(0.0)
+    mot.check_status()
+    assert got["tok_table"].dtype == torch.float32
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+    untouched = np.setdiff1d(np.arange(Vt), np.unique(toks))
+    assert not host(got["tok_table"])[untouched].any()
+    # accumulate semantics: a second call into the same buffers doubles them
+    into = {k: v.clone() for k, v in got.items() if v is not None and k in ("tok_table", "byte_table")}
+    if mode == "sum":
+        mot.functional.embed_mix_backward(cast(g), dev(toks), cast(Et), cast(Eb), mode="sum", bpt=bpt, ids_a=dev(ids), into=into, **kw)
+    else:
+        mot.functional.embed_mix_backward(cast(g), dev(toks), cast(Et), mode="noop", into=into, **kw)
+    assert rel(host(into["tok_table"]), 2 * ref["tok_table"]) < TOL
+
+
+def test_plain_backward_kernel_flags_bad_ids(mot):
+    """Out-of-range byte ids in the plain kernel's id path (one 8-byte load per lane + ds_bpermute): flagged in the status word, read
+    as row 0, never a fault; the other positions' gradients are unaffected."""
+    D, Db, bpt, Vt, B, T, seed = 768, 48, 16, 300, 2, 200, 9621
+    rs = np.random.RandomState(seed)
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.0)
+    ids = rs.randint(0, gi.BYTE_VOCAB, (B, T * bpt)).astype(np.int64)
+    bad = ids.copy()
+    bad[1, 5 * bpt + 3] = gi.BYTE_VOCAB + 7
+    bad[0, 17 * bpt] = -2
+    Et, Eb = f32(gi.normal_table(seed + 2, Vt, D)), f32(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+    g = f32(rs.standard_normal((B, T, D)))
+    clean = ids.copy(); clean[1, 5 * bpt + 3] = 0; clean[0, 17 * bpt] = 0
+    ref = orc.embed_mix_bwd(toks, clean, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt, dtype=np.float64,
+                            norm_out=True)
+    got = mot.functional.embed_mix_backward(dev(g), dev(toks), dev(Et), dev(Eb), mode="sum", bpt=bpt, ids_a=dev(bad), norm_out=True)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        mot.check_status()
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL and rel(host(got["byte_table"]), ref["byte_table"]) < TOL
