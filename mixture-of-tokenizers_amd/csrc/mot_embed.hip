@@ -458,7 +458,12 @@ static int dispatch_nch(const MixArgs &A, int dtype, int64_t blocks, size_t lds,
 // columns = 135 KB of the 160 KB).  So a workgroup owns one slice, keeps it in LDS for its whole life, and streams the same
 // slice of the token rows and of the output: the character rows are read from HBM/L2 once per workgroup instead of eight
 // times per token.  1024 threads (16 waves share the slice: one workgroup per CU by LDS), one wave per token, U tokens in flight.
-template <typename T, int U>
+// BPT: character slots per token as a compile-time constant (8: the reference's create_char_matrix, inference.py:290) or 0 = A.bpt at
+// run time; NORMB: the per-character rms factor is applied.  With both known the inner loop is straight-line: per character one
+// v_readlane of the row's byte offset (a constant lane), one v_add, one ds_read_b128, two v_pk_add_f32 -- round 2's loop over a
+// run-time bpt with its scalar multiplies, branches and per-flag selects issued ~100 instructions per token and wave, and without
+// its output stores the kernel still took 2.7 of its 6.0 ms: instruction issue, 16 waves per CU.
+template <typename T, int U, int BPT, bool NORMB>
 __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, int slice_cols, int nslices, int64_t tokens_per_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *tab = (T *)lds_raw;                                   // [byte_rows][slice_cols]
@@ -521,7 +526,11 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                     if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
                     tok = 0;
                 }
+#ifdef MOT_C5_NTLOAD   // dev variant: non-temporal loads of the token-row slices (each is read once)
+                ar_nx[u] = __builtin_nontemporal_load((const typename Elem<T>::raw *)(tok_table + (int64_t)tok * D + col0 + c));
+#else
                 ar_nx[u] = Elem<T>::load_raw(tok_table + (int64_t)tok * D + col0 + c);
+#endif
             }
             const int64_t at = (chunk + b) * A.bpt + lane;    // lane = (token of the batch, slot)
             id_nx = (lane < id_lanes && at < n_all * A.bpt) ? A.ids_a[at] : 0;
@@ -533,51 +542,50 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
             for (int u = 0; u < U; ++u) ar[u] = ar_nx[u];
             const int64_t idq = id_nx;
             if (b + U < nb) request(b + U);
-            // range check of the batch's ids, where they are used (one compare per lane; a bad id is flagged and reads row 0)
+            // range check of the batch's ids, where they are used (one compare per lane; a bad id is flagged and reads row 0); the
+            // lane keeps the BYTE OFFSET of its character's row inside the LDS slice
             const bool bad = (uint64_t)idq >= (uint64_t)A.byte_rows;
             if (bad && A.status) atomicOr(A.status, kStatusByteOor);
             const int idv = bad ? 0 : (int)idq;
+            const uint32_t row_bytes = (uint32_t)slice_cols * (uint32_t)sizeof(T);
+            const uint32_t offv = (uint32_t)idv * row_bytes;
+            const unsigned char *tabc = (const unsigned char *)tab + (size_t)c * sizeof(T);
+            const int bpt = BPT ? BPT : A.bpt;
+            // s_tok / s_byte are 1.0f when the scalars are absent (x * 1.0f is exact); the mean's 1 / bpt is folded into the character
+            // scalar when it is a power of two (exact), as for the 8 slots of the reference
+            const bool pow2 = (bpt & (bpt - 1)) == 0;
+            const float cb = pow2 ? inv_bpt * s_byte : s_byte;
+            T *orow = out + (chunk + b) * D + col0 + c;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t n = chunk + b + u;
-                // chars.mean(dim=-2), inference.py:267: four independent LDS reads per step (two accumulators keep the adds off one chain).
-                // The character ids of the batch sit one per lane; a slot's id is handed out with v_readlane (the slot index is
-                // wave-uniform), so the LDS row address is one scalar multiply + one add per character.  (Round 2 used __shfl here:
-                // a ds_bpermute per character on the LDS pipe that also carries the eight 1 KB row reads of a token -- without the
-                // output stores the kernel took 3.1 ms of its 6.3, half of it that.)
+                // chars.mean(dim=-2), inference.py:267: independent LDS reads, two accumulators keep the adds off one chain.  A slot's
+                // row offset is handed out with v_readlane (the slot's lane is a constant when BPT is)
                 vec_t acc0 = (vec_t)(0.f), acc1 = (vec_t)(0.f);
-                const int l0 = u * A.bpt;
-                const unsigned char *tabc = (const unsigned char *)tab + (size_t)c * sizeof(T);
-                const uint32_t row_bytes = (uint32_t)slice_cols * (uint32_t)sizeof(T);
-                int k = 0;
-                for (; k + 4 <= A.bpt; k += 4) {
-                    const int i0 = __builtin_amdgcn_readlane(idv, l0 + k), i1 = __builtin_amdgcn_readlane(idv, l0 + k + 1),
-                              i2 = __builtin_amdgcn_readlane(idv, l0 + k + 2), i3 = __builtin_amdgcn_readlane(idv, l0 + k + 3);
-                    vec_t v0 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i0 * row_bytes));
-                    vec_t v1 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i1 * row_bytes));
-                    vec_t v2 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i2 * row_bytes));
-                    vec_t v3 = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)i3 * row_bytes));
-                    if (A.norm_byte) { v0 *= A.byte_rnorm[i0]; v1 *= A.byte_rnorm[i1]; v2 *= A.byte_rnorm[i2]; v3 *= A.byte_rnorm[i3]; }
-                    acc0 += v0; acc1 += v1; acc0 += v2; acc1 += v3;
+                const int l0 = u * bpt;
+                auto one = [&](int k, vec_t &acc) {
+                    const uint32_t so = (uint32_t)__builtin_amdgcn_readlane((int)offv, l0 + k);
+                    vec_t v = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + so));
+                    if (NORMB) v *= A.byte_rnorm[__builtin_amdgcn_readlane(idv, l0 + k)];
+                    acc += v;
+                };
+                if constexpr (BPT > 0) {
+#pragma unroll
+                    for (int k = 0; k < BPT; ++k) one(k, (k & 1) ? acc1 : acc0);
+                } else {
+                    int k = 0;
+                    for (; k + 2 <= bpt; k += 2) { one(k, acc0); one(k + 1, acc1); }
+                    if (k < bpt) one(k, acc0);
                 }
-                for (; k < A.bpt; ++k) {
-                    const int id = __builtin_amdgcn_readlane(idv, l0 + k);
-                    vec_t v = Elem<T>::widen(*(const typename Elem<T>::raw *)(tabc + (uint32_t)id * row_bytes));
-                    if (A.norm_byte) v *= A.byte_rnorm[id];
-                    acc0 += v;
-                }
-                const vec_t acc = acc0 + acc1;
-                vec_t a = Elem<T>::widen(ar[u]);
-                if (A.scale_tok) a *= s_tok;
-                const vec_t bsum = acc * inv_bpt;             // exact for the power-of-two slot counts of the reference (8), else within an ulp of acc / bpt
-                const vec_t x = a + (A.scale_byte ? bsum * s_byte : bsum);
+                vec_t acc = acc0 + acc1;
+                if (!pow2) acc = acc * inv_bpt;               // within an ulp of acc / bpt for the other slot counts
+                const vec_t x = Elem<T>::widen(ar[u]) * s_tok + acc * cb;
 #ifdef MOT_C5_NOSTORE   // dev, timing only: everything but the output stores
                 if (b + u < nb && x[0] == 123.456f) {
 #else
                 if (b + u < nb) {
 #endif
-                    if (MOT_C5_STORE == 1) *(typename Elem<T>::raw *)(out + n * D + col0 + c) = __builtin_convertvector(x, typename Elem<T>::raw);
-                    else Elem<T>::storev_nt(out + n * D + col0 + c, x);
+                    if (MOT_C5_STORE == 1) *(typename Elem<T>::raw *)(orow + (int64_t)u * D) = __builtin_convertvector(x, typename Elem<T>::raw);
+                    else Elem<T>::storev_nt(orow + (int64_t)u * D, x);
                 }
             }
         }
@@ -596,8 +604,17 @@ static int launch_mean_lds(MixArgs A, const MotEmbedMixDesc &d, int slice_cols, 
     const size_t lds = (size_t)d.byte_rows * slice_cols * sizeof(T);
     static std::atomic<uint64_t> lds_ok{0};   // per-device bits
     constexpr int kMeanU = 4;   // token-row slices in flight per wave (8 spilled before the loop was pipelined; no effect since)
-    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU>, lds_ok, "embed_mean_lds_kernel")) return rc_lds;
-    hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
+#define MOT_MEAN_LAUNCH(BPT, NORMB)                                                                                                          \
+    do {                                                                                                                                    \
+        static std::atomic<uint64_t> ok_{0};   /* per-device bits */                                                                        \
+        if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU, BPT, NORMB>, ok_, "embed_mean_lds_kernel")) return rc_lds; \
+        hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU, BPT, NORMB>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, \
+                           nslices, per);                                                                                                   \
+    } while (0)
+    (void)lds_ok;
+    if (d.bpt == 8) { if (d.norm_byte) MOT_MEAN_LAUNCH(8, true); else MOT_MEAN_LAUNCH(8, false); }
+    else { if (d.norm_byte) MOT_MEAN_LAUNCH(0, true); else MOT_MEAN_LAUNCH(0, false); }
+#undef MOT_MEAN_LAUNCH
     return check_launch("embed_mean_lds_kernel");
 }
 
