@@ -707,3 +707,42 @@ def test_plain_backward_kernel_flags_bad_ids(mot):
     with pytest.raises(IndexError):
         mot.check_status()
     assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL and rel(host(got["byte_table"]), ref["byte_table"]) < TOL
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("D,Db,bpt,mode,B,T,Vt,seed", [
+    (256, 16, 16, "sum", 48, 2048, 3000, 9651),          # 98 304 positions: every workgroup and wave has a full stretch
+    (768, 0, 0, "noop", 96, 1024, 20000, 9652),          # tokens-only, many short runs: a flush every few places
+    (512, 32, 16, "sum", 64, 2048, 7, 9653),             # seven tokens: runs far longer than a wave's stretch (rows shared by every wave)
+])
+def test_plain_backward_kernel_large_batches(mot, dtype, D, Db, bpt, mode, B, T, Vt, seed):
+    """embed_mix_bwd_plain_kernel on batches that fill the chip (all 256 workgroups, 128-place segments, runs cut by stretch
+    boundaries, runs of length one): same bar against the float64 oracle.  (Written for the flusher-wave variant of round 3 -- one wave
+    issuing the atomic row-adds of the other eleven through LDS mailboxes; correct, 20 % slower, not kept: DESIGN.md section 3.)"""
+    rs = np.random.RandomState(seed)
+    bf = dtype == "bf16"
+    rnd = (lambda a: orc.bf16_round(a)) if bf else f32
+    cast = (lambda a: dev(a).bfloat16()) if bf else dev
+    toks = gi.fineweb_like_tokens(seed, B, T, vocab=Vt, eot_p=0.0)
+    Et = rnd(gi.normal_table(seed + 2, Vt, D))
+    g = rnd(rs.standard_normal((B, T, D)))
+    if bf:
+        orc.set_eps(2.0 ** -7)
+    try:
+        if mode == "sum":
+            Eb = rnd(gi.normal_table(seed + 3, gi.BYTE_VOCAB, Db))
+            ids = rs.randint(0, 256, (B, T * bpt)).astype(np.int64)
+            ref = orc.embed_mix_bwd(toks, ids, None, Et.astype(np.float64), Eb.astype(np.float64), g.astype(np.float64), mode="sum", bpt=bpt,
+                                    dtype=np.float64, norm_out=True)
+            got = mot.functional.embed_mix_backward(cast(g), dev(toks), cast(Et), cast(Eb), mode="sum", bpt=bpt, ids_a=dev(ids), norm_out=True)
+            assert rel(host(got["byte_table"]), ref["byte_table"]) < TOL
+        else:
+            ref = orc.embed_mix_bwd(toks, None, None, Et.astype(np.float64), None, g.astype(np.float64), mode="noop", bpt=0, dtype=np.float64, norm_out=True)
+            got = mot.functional.embed_mix_backward(cast(g), dev(toks), cast(Et), mode="noop", norm_out=True)
+    finally:
+        orc.set_eps(0.0)
+    torch.cuda.synchronize()
+    mot.check_status()
+    assert rel(host(got["tok_table"]), ref["tok_table"]) < TOL
+    untouched = np.setdiff1d(np.arange(Vt), np.unique(toks))
+    assert not host(got["tok_table"])[untouched].any()

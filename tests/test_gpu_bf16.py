@@ -415,7 +415,10 @@ def test_bf16_mean_backward_vs_oracle(mot, D, bpt, Vt, Vc, B, T, kw, seed):
     pt, pc = torch.nn.Parameter(dev(Et).bfloat16()), torch.nn.Parameter(dev(Ec).bfloat16())
     x = mot.embed_mix(dev(toks), pt, pc, mode="mean", bpt=bpt, ids_a=dev(ids), **gkw)
     x.backward(dev(g).bfloat16())
-    assert pt.grad.dtype == torch.bfloat16 and torch.equal(pt.grad, got["tok_table"].to(torch.bfloat16))
+    # (a second run: float atomics make the last bits order-dependent, so the comparison is one bf16 step, not bitwise)
+    assert pt.grad.dtype == torch.bfloat16
+    a, b_ = host(pt.grad.float()), host(got["tok_table"].to(torch.bfloat16).float())
+    assert (np.abs(a - b_) <= 2.0 ** -7 * np.maximum(np.abs(b_), 1e-3)).all()
 
 
 @pytest.mark.parametrize("Dt,Db,bpt,Dm,Vt,B,T,kw,seed", [
