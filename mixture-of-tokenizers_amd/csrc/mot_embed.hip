@@ -470,21 +470,11 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
     constexpr int VEC = Elem<T>::kVec;
     typedef typename Elem<T>::vec vec_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifndef MOT_C5_MAP
-#define MOT_C5_MAP 0
-#endif
-#ifndef MOT_C5_STORE
-#define MOT_C5_STORE 0
-#endif
-    int slice = blockIdx.x % nslices;
-    int64_t part = blockIdx.x / nslices;
-    if (MOT_C5_MAP == 1 && (gridDim.x / nslices) % 8 == 0) {
-        // dev variant: the nslices workgroups of one token partition on ONE XCD (workgroups b and b + 8 share an XCD): the eight
-        // 1 KB pieces of an 8 KB output row then pass through one L2
-        const int x = blockIdx.x & 7, k = blockIdx.x >> 3;
-        slice = k % nslices;
-        part = (int64_t)x * ((gridDim.x / nslices) / 8) + k / nslices;
-    }
+    // (The nslices workgroups of a token partition are consecutive block ids, i.e. on nslices DIFFERENT XCDs.  Placing them on one
+    //  XCD, default-policy stores and non-temporal loads of the token rows were all measured in round 3 and all lost:
+    //  profiles/r03_c5_variants.txt, built from commit 0312ce5 and its successors with -DMOT_C5_MAP / _STORE / _NTLOAD.)
+    const int slice = blockIdx.x % nslices;
+    const int64_t part = blockIdx.x / nslices;
     const int col0 = slice * slice_cols;
     const int D = A.Dt;
     const T *byte_table = (const T *)A.byte_table, *tok_table = (const T *)A.tok_table;
@@ -526,11 +516,7 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                     if (A.status && lane == 0) atomicOr(A.status, kStatusTokenOor);
                     tok = 0;
                 }
-#ifdef MOT_C5_NTLOAD   // dev variant: non-temporal loads of the token-row slices (each is read once)
-                ar_nx[u] = __builtin_nontemporal_load((const typename Elem<T>::raw *)(tok_table + (int64_t)tok * D + col0 + c));
-#else
                 ar_nx[u] = Elem<T>::load_raw(tok_table + (int64_t)tok * D + col0 + c);
-#endif
             }
             const int64_t at = (chunk + b) * A.bpt + lane;    // lane = (token of the batch, slot)
             id_nx = (lane < id_lanes && at < n_all * A.bpt) ? A.ids_a[at] : 0;
@@ -579,14 +565,12 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                 vec_t acc = acc0 + acc1;
                 if (!pow2) acc = acc * inv_bpt;               // within an ulp of acc / bpt for the other slot counts
                 const vec_t x = Elem<T>::widen(ar[u]) * s_tok + acc * cb;
-#ifdef MOT_C5_NOSTORE   // dev, timing only: everything but the output stores
-                if (b + u < nb && x[0] == 123.456f) {
+#ifdef MOT_C5_NOSTORE   // dev, timing only: everything but the output stores (tools/variants.sh c5_nostore:"-DMOT_C5_NOSTORE")
+                if (b + u < nb && x[0] == 123.456f)
 #else
-                if (b + u < nb) {
+                if (b + u < nb)
 #endif
-                    if (MOT_C5_STORE == 1) *(typename Elem<T>::raw *)(orow + (int64_t)u * D) = __builtin_convertvector(x, typename Elem<T>::raw);
-                    else Elem<T>::storev_nt(orow + (int64_t)u * D, x);
-                }
+                    Elem<T>::storev_nt(orow + (int64_t)u * D, x);
             }
         }
     }
