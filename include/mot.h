@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 10
+#define MOT_ABI_VERSION 11
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -334,6 +334,13 @@ typedef struct MotCrossAttnDesc {
     /* optional: buffer of 2 * n_tokens * n_heads * 128 floats.  The forward leaves the projected queries and the attention
      * output there; the backward, given the same buffer, reads them instead of recomputing that part of the forward. */
     void *saved_qy;
+    /* MOT_F32 (0) or MOT_BF16: where the products over the tokens run (q = W_q xq, out = c_proj y; backward: dW_p, dy, dW_q, dxq).
+     * MOT_BF16 = the bf16 MFMA with fp32 accumulation: their row operands (xq, y, grad_out, dq) are rounded to bf16 first and the
+     * weights are taken as bf16 -- the values those operands have in the reference's production cast (CastedLinear and
+     * `self.q_w.type_as(x)`, train_gpt.py:185-186, 277-278; x bf16 since 1124-1126); tables, attention and every result stay
+     * fp32.  Needs dim % 8 == 0.  Workspace sizes depend on it. */
+    int32_t matmul_dtype;
+    int32_t reserved0;
 } MotCrossAttnDesc;
 
 /*

@@ -145,7 +145,19 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
 
 // ------------------------------------------------------------------------------------------ host
 // workspace, in floats: [q: T*HD][y: T*HD][kt: R*HD][vt: R*HD][xkv: R*D (dual: R = T*bpt)][xq: D > HD ? T*D : 0]
-struct AttnLayout { size_t q, y, kt, vt, xkv, xq, total; int64_t R; };
+struct AttnLayout { size_t q, y, kt, vt, xkv, xq, a16, w16, total; int64_t R; };
+// matmul_dtype == MOT_BF16: the two products over the tokens (q = W_q xq, out = c_proj y) run on the bf16 MFMA
+// (launch_gemm_rows_bf16, fp32 accumulation and fp32 results): their row operands are rounded to bf16 first -- the reference's own
+// rounding points in the production cast (xq is a bf16 tensor out of norm(), y one out of the attention, train_gpt.py:277, 292-293;
+// the weights are cast where they are used, 185-186, 277-278) -- everything else stays as it is.
+static bool mm16(const MotCrossAttnDesc &d) { return d.matmul_dtype == MOT_BF16; }
+// out[n][Nc] = A[n][R] . W[Nc][R]^T: A, W fp32 -> bf16 copies in a16 / w16 -> bf16 MFMA, fp32 out
+static int dense_rows_bf16(const float *A, int64_t n, int R, const float *W, int Nc, float *out, void *a16, void *w16, hipStream_t stream) {
+    int rc;
+    if ((rc = launch_narrow(A, n * R, a16, stream))) return rc;
+    if ((rc = launch_narrow(W, (int64_t)Nc * R, w16, stream))) return rc;
+    return launch_gemm_rows_bf16(a16, R, n, w16, R, R, Nc, out, Nc, false, nullptr, stream);
+}
 
 static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     AttnLayout L;
@@ -157,6 +169,9 @@ static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     L.q = take(T * HD); L.y = take(T * HD); L.kt = take((size_t)L.R * HD); L.vt = take((size_t)L.R * HD);
     L.xkv = take(dual ? T * d.bpt * D : (size_t)L.R * D);   // the (normalised) key/value source rows: per kv position, or per byte-table row
     L.xq = take(D > HD ? T * D : 0);   // the gathered query rows live in y's place until the attention writes y
+    const size_t wide = D > HD ? D : HD;
+    L.a16 = take(mm16(d) ? (T * wide + 1) / 2 : 0);   // bf16 copies: the row operand of a product, its weight
+    L.w16 = take(mm16(d) ? (HD * D + 1) / 2 : 0);
     L.total = o;
     return L;
 }
@@ -189,7 +204,9 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     float *xq = D > HD ? ws + L.xq : y;
     if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, (int)D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
         return rc;
-    if ((rc = launch_gemm_rows(xq, (int)D, T, (const float *)d.q_w, (int)D, (int)D, (int)HD, q, (int)HD, true, stream))) return rc;
+    if (mm16(d)) rc = dense_rows_bf16(xq, T, D, (const float *)d.q_w, HD, q, ws + L.a16, ws + L.w16, stream);
+    else rc = launch_gemm_rows(xq, (int)D, T, (const float *)d.q_w, (int)D, (int)D, (int)HD, q, (int)HD, true, stream);
+    if (rc) return rc;
     // 2. key/value rows: per byte-table row, or per kv position when the embedding is norm(E[a] + E[b])
     const int kv_norm = d.norm_byte;
     if (dual) {
@@ -218,6 +235,7 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
     if ((rc = check_launch("cross_attn_kernel"))) return rc;
     // 4. out = c_proj y                   (line 293): out[t][c] = sum_r y[t][r] * proj_w[c][r]
+    if (mm16(d)) return dense_rows_bf16(y, T, HD, (const float *)d.proj_w, D, (float *)d.out, ws + L.a16, ws + L.w16, stream);
     return launch_gemm_rows(y, (int)HD, T, (const float *)d.proj_w, (int)HD, (int)HD, (int)D, (float *)d.out, (int)D, true, stream);
 }
 
@@ -561,7 +579,7 @@ __global__ __launch_bounds__(kThreads) void iota_i32_kernel(int32_t *__restrict_
 
 // workspace of the backward, in floats
 struct AttnBwdLayout {
-    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, emb, emb_bytes, total;
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, emb, emb_bytes, b0, b1, w16, total;
 };
 static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
     memset(&e, 0, sizeof(e));
@@ -602,6 +620,8 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     }
     L.emb_bytes = a > b ? a : b;
     L.emb = take((L.emb_bytes + 3) / 4);
+    const size_t wide = D > HD ? D : HD;   // matmul_dtype == MOT_BF16: two bf16 row operands and one (transposed) weight at a time
+    L.b0 = take(mm16(d) ? (T * wide + 1) / 2 : 0); L.b1 = take(mm16(d) ? (T * wide + 1) / 2 : 0); L.w16 = take(mm16(d) ? (HD * D + 1) / 2 : 0);
     L.total = o;
     return L;
 }
@@ -642,7 +662,9 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         y = q + (size_t)T * HD;
     } else {
         if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream))) return rc;
-        if ((rc = launch_gemm_rows(xq, D, T, (const float *)d.q_w, D, D, HD, q, HD, true, stream))) return rc;
+        if (mm16(d)) rc = dense_rows_bf16(xq, T, D, (const float *)d.q_w, HD, q, ws + L.b0, ws + L.w16, stream);
+        else rc = launch_gemm_rows(xq, D, T, (const float *)d.q_w, D, D, HD, q, HD, true, stream);
+        if (rc) return rc;
         have_xq = true;
     }
     const float *kv_w = (const float *)d.kv_w;
@@ -668,8 +690,21 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         if ((rc = check_launch("cross_attn_kernel"))) return rc;
     }
     // ---- c_proj:  dW_p += g^T y;  dy = g W_p   (proj_w [D, HD] is the k-major operand of g[T, D] -> dy[T, HD])
-    if (gr.d_proj_w && (rc = launch_gemm_tn(g_out, D, D, y, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
-    if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, stream))) return rc;
+    // (matmul_dtype == MOT_BF16: the four products over the tokens -- dW_p, dy, dW_q, dxq -- on the bf16 MFMA, row operands rounded
+    //  to bf16 as the reference's bf16 autograd has them, fp32 sums; b0 = g, then xq; b1 = y, then dq; w16 = the k-major weight)
+    __bf16 *b0 = (__bf16 *)(ws + L.b0), *b1 = (__bf16 *)(ws + L.b1), *w16 = (__bf16 *)(ws + L.w16);
+    if (mm16(d)) {
+        if ((rc = launch_narrow(g_out, T * D, b0, stream))) return rc;
+        if (gr.d_proj_w) {
+            if ((rc = launch_narrow(y, T * HD, b1, stream))) return rc;
+            if ((rc = launch_gemm_tn_bf16(b0, D, D, b1, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
+        }
+        if ((rc = launch_narrow_transpose((const float *)d.proj_w, D, HD, w16, stream))) return rc;   // [HD][D]
+        if ((rc = launch_gemm_rows_bf16(b0, D, T, w16, D, D, HD, dy, HD, false, nullptr, stream))) return rc;
+    } else {
+        if (gr.d_proj_w && (rc = launch_gemm_tn(g_out, D, D, y, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
+        if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, stream))) return rc;
+    }
     // ---- attention
     AttnBwdArgs B;
     B.q_pre = q; B.dy = dy; B.kn = kn; B.vpre = vpre; B.lambda = d.lambda_factor; B.ids = dual ? nullptr : d.ids_a; B.rows = R; B.T = T; B.bpt = d.bpt; B.H = H;
@@ -729,13 +764,20 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         if ((rc = check_launch("byte_rows_bwd_kernel"))) return rc;
     }
     // ---- q_w and the token table
+    if (mm16(d) && (gr.d_q_w || gr.d_tok_table) && (rc = launch_narrow(dq, T * HD, b1, stream))) return rc;
     if (gr.d_q_w) {
         if (!have_xq && (rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
             return rc;
-        if ((rc = launch_gemm_tn(dq, HD, HD, xq, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
+        if (mm16(d)) {
+            if ((rc = launch_narrow(xq, T * D, b0, stream))) return rc;
+            if ((rc = launch_gemm_tn_bf16(b1, HD, HD, b0, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
+        } else if ((rc = launch_gemm_tn(dq, HD, HD, xq, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
     }
     if (gr.d_tok_table) {
-        if ((rc = dense_gemm_kmajor(dq, T, HD, (const float *)d.q_w, D, dxq, stream))) return rc;   // q_w [HD, D]
+        if (mm16(d)) {
+            if ((rc = launch_narrow_transpose((const float *)d.q_w, HD, D, w16, stream))) return rc;   // [D][HD]
+            if ((rc = launch_gemm_rows_bf16(b1, HD, T, w16, HD, HD, D, dxq, D, false, nullptr, stream))) return rc;
+        } else if ((rc = dense_gemm_kmajor(dq, T, HD, (const float *)d.q_w, D, dxq, stream))) return rc;   // q_w [HD, D]
         noop_bwd_desc(ed, d.tokens, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, d.status);
         ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
         eg.grad_out = dxq; eg.d_tok_table = gr.d_tok_table;

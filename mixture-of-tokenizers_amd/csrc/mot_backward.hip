@@ -2237,7 +2237,7 @@ __global__ __launch_bounds__(kTnThreads) void gemm_tn_bf16_kernel(const __bf16 *
 }
 
 // A, B: 16-byte aligned, lda / ldb / M / Kc multiples of 8
-static int launch_gemm_tn_bf16(const __bf16 *A_, int lda, int M, const __bf16 *B_, int ldb, int Kc, int64_t rows, float *C, int ldc, hipStream_t stream) {
+int launch_gemm_tn_bf16(const __bf16 *A_, int lda, int M, const __bf16 *B_, int ldb, int Kc, int64_t rows, float *C, int ldc, hipStream_t stream) {
     if (M <= 0 || Kc <= 0 || rows <= 0) return MOT_OK;
     const int tiles = ((M + 127) / 128) * ((Kc + 127) / 128);
     // contraction slices: two workgroups per CU (80 KB of LDS each), a multiple of 8 for the XCD mapping, few enough to keep the
@@ -2267,6 +2267,32 @@ __global__ __launch_bounds__(kThreads) void transpose_bf16_kernel(const __bf16 *
     __syncthreads();
     for (int c = ty; c < 32; c += 8)
         if (c0 + c < cols && r0 + tx < rows) dst[(int64_t)(c0 + c) * rows + r0 + tx] = tile[tx][c];
+}
+
+// dst[c][r] = bf16(src[r][c])   (fp32 rows x cols -> bf16 cols x rows): the k-major copy of a weight for gemm_rows_bf16
+__global__ __launch_bounds__(kThreads) void narrow_transpose_kernel(const float *__restrict__ src, int rows, int cols, __bf16 *__restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int r = ty; r < 32; r += 8)
+        tile[r][tx] = (r0 + r < rows && c0 + tx < cols) ? src[(int64_t)(r0 + r) * cols + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int c = ty; c < 32; c += 8)
+        if (c0 + c < cols && r0 + tx < rows) dst[(int64_t)(c0 + c) * rows + r0 + tx] = (__bf16)tile[tx][c];
+}
+int launch_narrow_transpose(const float *src, int rows, int cols, void *dst, hipStream_t stream) {
+    if (rows <= 0 || cols <= 0) return MOT_OK;
+    hipLaunchKernelGGL(narrow_transpose_kernel, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(kThreads), 0, stream, src, rows, cols,
+                       (__bf16 *)dst);
+    return check_launch("narrow_transpose_kernel");
+}
+// dst[i] = bf16(src[i]); both 16-byte aligned
+int launch_narrow(const float *src, int64_t n, void *dst, hipStream_t stream) {
+    if (n <= 0) return MOT_OK;
+    size_t nb = ((size_t)n / 8 + kThreads) / kThreads;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(narrow_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, src, n, (__bf16 *)dst);
+    return check_launch("narrow_kernel");
 }
 
 static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }

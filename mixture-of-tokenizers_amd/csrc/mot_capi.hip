@@ -275,6 +275,8 @@ static int validate_cross_attn(const MotCrossAttnDesc *d) {
     if (d->n_heads < 1 || d->dim < 128 || d->n_heads * 128 > d->dim)
         return set_error(MOT_ESHAPE, "cross_attn: n_heads %d x 128 does not fit dim %d (train_gpt.py:457-459: heads = dim // 128)", d->n_heads, d->dim);
     if ((d->dim & 3) || d->dim > 1024) return set_error(MOT_EUNSUPPORTED, "cross_attn: dim %d must be a multiple of 4 and <= 1024", d->dim);
+    if (d->matmul_dtype != MOT_F32 && d->matmul_dtype != MOT_BF16) return set_error(MOT_EINVAL, "cross_attn: bad matmul_dtype %d", d->matmul_dtype);
+    if (d->matmul_dtype == MOT_BF16 && (d->dim & 7)) return set_error(MOT_EUNSUPPORTED, "cross_attn: matmul_dtype bf16 needs dim %% 8 == 0 (got %d)", d->dim);
     if (d->head_layout != MOT_HEADS_AS_VIEWED && d->head_layout != MOT_HEADS_PER_TOKEN)
         return set_error(MOT_EINVAL, "cross_attn: bad head_layout %d", d->head_layout);
     if (!d->tokens || !d->ids_a || !d->tok_table || !d->byte_table || !d->q_w || !d->kv_w || !d->proj_w || !d->lambda_factor || !d->out)

@@ -578,17 +578,22 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
 
 
 def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                     bpt, n_heads, norm_tok, norm_byte, head_layout, eps):
+                     bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul=None):
     """Validated MotCrossAttnDesc for both directions; returns (desc, keepalive list, device, T, D)."""
     dev = capi.require_device(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k)
     T = tokens.shape[1]
     tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
     tok = tok if tok.is_contiguous() else tok.contiguous()
     f32 = torch.float32
-    # bf16 tables (the production cast, train_gpt.py:1124-1126): the kernels of this mixin are fp32, so the operands are widened
-    # once per call -- the tables as they are (bf16 values), the fp32 master weights rounded to bf16 first, as
-    # `self.q_w.type_as(x)` does (lines 277-278, 185-186) -- and the result is rounded once to bf16 by the caller
+    # bf16 tables (the production cast, train_gpt.py:1124-1126): the attention kernels of this mixin are fp32, so the operands are
+    # widened once per call -- the tables as they are (bf16 values), the fp32 master weights rounded to bf16 first, as
+    # `self.q_w.type_as(x)` does (lines 277-278, 185-186) -- and the result is rounded once to bf16 by the caller.  The products
+    # over the tokens (q, c_proj and their four backward products) then run on the bf16 MFMA (`matmul_dtype`, include/mot.h):
+    # their row operands are bf16 tensors in the reference too.  `matmul="fp32"` keeps them on the fp32 MFMA.
     bf = tok_table.dtype == torch.bfloat16
+    if matmul not in (None, "fp32", "bf16"):
+        raise ValueError(f"cross_attn: matmul must be None, 'fp32' or 'bf16' (got {matmul!r})")
+    mm_bf16 = (bf and tok_table.shape[1] % 8 == 0) if matmul is None else matmul == "bf16"
     if byte_table.dtype != tok_table.dtype:
         raise TypeError(f"cross_attn: byte table is {byte_table.dtype} but the token table is {tok_table.dtype}")
     wide = (lambda t: t.detach().float()) if bf else (lambda t: t.detach())
@@ -612,6 +617,7 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
     d = capi.MotCrossAttnDesc()
     d.struct_size = C.sizeof(capi.MotCrossAttnDesc)
     d.dtype, d.n_tokens, d.bpt, d.n_heads, d.dim = capi.F32, T, int(bpt), int(n_heads), D
+    d.matmul_dtype = capi.BF16 if mm_bf16 else capi.F32
     d.head_layout = {"as_viewed": capi.HEADS_AS_VIEWED, "per_token": capi.HEADS_PER_TOKEN}[head_layout]
     d.tokens, d.ids_a, d.ids_b = capi.ptr(tok), capi.ptr(ia), capi.ptr(ib)
     d.tok_table, d.tok_rows, d.byte_table, d.byte_rows = capi.ptr(tt), tt.shape[0], capi.ptr(bt), bt.shape[0]
@@ -650,14 +656,15 @@ class _CrossAttnFn(torch.autograd.Function):
 
 @torch.compiler.disable
 def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                        bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, saved_qy=None, ids_b=None) -> dict:
+                        bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, saved_qy=None, ids_b=None,
+                        matmul=None) -> dict:
     """One call of mot_cross_attn_bwd: dense fp32 gradients {tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor}.
     `saved_qy`: the buffer the forward filled (projected queries + attention output); without it they are recomputed.
     `ids_b`: the second id tensor of the add_padded_and_pulled embedding (train_gpt.py:364-372)."""
     if tokens.ndim == 1:
         tokens = tokens[None]
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps)
+                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul)
     g = _contig(grad_out.reshape(T, D).float(), torch.float32, "grad_out")
     out = {"tok_table": torch.zeros_like(keep[1]), "byte_table": torch.zeros_like(keep[2]), "q_w": torch.zeros_like(keep[3]),
            "kv_w": torch.zeros_like(keep[4]), "proj_w": torch.zeros_like(keep[5]), "lambda_factor": torch.zeros(1, dtype=torch.float32, device=dev)}
@@ -677,9 +684,9 @@ def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, 
 
 
 def _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k, *,
-                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None, saved_qy=None):
+                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None, saved_qy=None, matmul=None):
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps)
+                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul)
     out = torch.empty((1, T, D), dtype=torch.float32, device=dev)
     d.out = capi.ptr(out)
     if saved_qy is not None:
@@ -705,17 +712,20 @@ def cross_attn(tokens: torch.Tensor, ids_a: torch.Tensor, tok_table: torch.Tenso
                q_w: torch.Tensor, kv_w: torch.Tensor, proj_w: torch.Tensor, lambda_factor: torch.Tensor,
                cos_q: torch.Tensor, sin_q: torch.Tensor, cos_k: torch.Tensor, sin_k: torch.Tensor,
                bpt: int, n_heads: int, ids_b: torch.Tensor | None = None, norm_tok: bool = True, norm_byte: bool = True,
-               head_layout: str = "as_viewed", eps: float | None = None, kv_cache: dict | None = None) -> torch.Tensor:
+               head_layout: str = "as_viewed", eps: float | None = None, kv_cache: dict | None = None,
+               matmul: str | None = None) -> torch.Tensor:
     """The cross-attention byte mixin on top of the two embedding gathers (train_gpt.py:342-379, 446-464, 271-300):
     tokens (1, T) -> (1, T, dim).  The reference asserts batch 1 (line 275).  fp32.  With autograd enabled and
     differentiable parameters it records one backward node (either embedding: one id tensor, or norm(emb(padded) + emb(pulled))).
     head_layout "as_viewed" reproduces the reference's reshape of k and v (lines 283-284); "per_token" is the
-    rearrange its comment names.  bfloat16 tables are accepted (operands widened once per call, fp32 arithmetic, bf16 result and
-    table gradients)."""
+    rearrange its comment names.  bfloat16 tables are accepted (operands widened once per call, bf16 result and table gradients):
+    the attention itself stays fp32, the products over the tokens -- q, c_proj and their backward products -- then run on the
+    bf16 MFMA with fp32 accumulation, their row operands rounded to bf16 where the reference's are bf16 tensors
+    (`matmul="fp32"` keeps them on the fp32 MFMA; `matmul="bf16"` asks for the bf16 MFMA with fp32 tables too)."""
     if tokens.ndim == 1:
         tokens = tokens[None]
     assert tokens.shape[0] == 1, "Must use batch size = 1 for FlexAttention"      # train_gpt.py:275
-    kw = dict(bpt=bpt, n_heads=n_heads, norm_tok=norm_tok, norm_byte=norm_byte, head_layout=head_layout, eps=eps)
+    kw = dict(bpt=bpt, n_heads=n_heads, norm_tok=norm_tok, norm_byte=norm_byte, head_layout=head_layout, eps=eps, matmul=matmul)
     params = (tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return _CrossAttnFn.apply(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, ids_b, (cos_q, sin_q, cos_k, sin_k), kw)

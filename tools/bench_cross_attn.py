@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--dual", action="store_true")
     ap.add_argument("--backward", action="store_true", help="time forward + backward through autograd")
     ap.add_argument("--kv-cache", action="store_true", help="inference: keep the per-byte-row K/V tables across calls")
+    ap.add_argument("--bf16", action="store_true", help="bfloat16 tables (the production cast)")
+    ap.add_argument("--matmul", default=None, choices=["fp32", "bf16"], help="where the products over the tokens run (default: bf16 MFMA with bf16 tables)")
     a = ap.parse_args()
     import mixture_of_tokenizers_amd as mot
     from mixture_of_tokenizers_amd.modules import Rotary
@@ -32,6 +34,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1)
     Et = torch.randn((50257, D), generator=g, device=dev)
     Eb = torch.randn((458, D), generator=g, device=dev)
+    if a.bf16:
+        Et, Eb = Et.bfloat16(), Eb.bfloat16()
     bound = (3 ** 0.5) * 0.5 * D ** -0.5
     q_w = (torch.rand((D, D), generator=g, device=dev) * 2 - 1) * bound
     kv_w = (torch.rand((2, D, D), generator=g, device=dev) * 2 - 1) * bound
@@ -43,11 +47,11 @@ def main():
     pulled = dc.pull_from_left(padded, bpt, 456, 457)
     rq, rk = Rotary(128, T).to(dev), Rotary(128, T * bpt).to(dev)
     kw = dict(q_w=q_w, kv_w=kv_w, proj_w=p_w, lambda_factor=torch.tensor(0.5, device=dev), cos_q=rq.cos, sin_q=rq.sin,
-              cos_k=rk.cos, sin_k=rk.sin, bpt=bpt, n_heads=H, head_layout=a.layout, ids_b=padded if a.dual else None)
+              cos_k=rk.cos, sin_k=rk.sin, bpt=bpt, n_heads=H, head_layout=a.layout, ids_b=padded if a.dual else None, matmul=a.matmul)
     if a.backward:
         for t in (Et, Eb, q_w, kv_w, p_w, kw["lambda_factor"]):
             t.requires_grad_(True)
-        go = torch.randn((1, T, D), generator=g, device=dev)
+        go = torch.randn((1, T, D), generator=g, device=dev).to(Et.dtype)
 
         def run():
             x = mot.functional.cross_attn(toks, pulled, Et, Eb, **kw)
@@ -70,7 +74,8 @@ def main():
     mot.check_status()
     ms = e0.elapsed_time(e1) / a.steps
     flops = 2.0 * T * D * D * 2 + (2.0 * T * bpt * D * D * 2 if a.dual else 2.0 * 458 * D * D * 2)
-    print(json.dumps({"backward": a.backward, "workload": f"cross_attn T={T} d={D} bpt={bpt} heads={H} layout={a.layout} dual={a.dual}", "ms": ms,
+    print(json.dumps({"backward": a.backward, "tables": str(Et.dtype), "matmul": a.matmul or ("bf16" if a.bf16 else "fp32"),
+                      "workload": f"cross_attn T={T} d={D} bpt={bpt} heads={H} layout={a.layout} dual={a.dual}", "ms": ms,
                       "tokens_per_s": T / (ms * 1e-3), "gemm_tflops": flops / (ms * 1e-3) / 1e12,
                       "reference_flops_ratio": (2.0 * T * D * D * 2 + 2.0 * T * bpt * D * D * 2) / flops,
                       "finite": bool(torch.isfinite(x).all())}))
