@@ -409,6 +409,11 @@ typedef struct MotCharSwaDesc {
     uint32_t *status;           /* optional, as in MotEmbedMixDesc */
     void *workspace;            /* mot_char_swa_workspace_bytes(desc) */
     size_t workspace_bytes;
+    /* MOT_F32 (0) or MOT_BF16: where the two products over the tokens run (xq = wq xn, h = wo y).  MOT_BF16 = the bf16 MFMA with
+     * fp32 accumulation, xn and y rounded to bf16 first and the weights taken as bf16 (for callers whose tables and weights
+     * hold bf16 values; the reference script runs in float32); needs dim % 8 == 0 and (heads * head_dim) % 8 == 0. */
+    int32_t matmul_dtype;
+    int32_t reserved0;
 } MotCharSwaDesc;
 
 size_t mot_char_swa_desc_size(void);

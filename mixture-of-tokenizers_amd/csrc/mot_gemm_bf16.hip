@@ -21,7 +21,7 @@ constexpr int kGRow = 2 * kGK + 16; // bytes per staged row
 
 template <bool OUT_BF16, int WM>   // WM waves along the rows x 2 along the columns: a (64 WM) x 128 output block per workgroup
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3, 4))) void gemm_rows_bf16_kernel(const __bf16 *__restrict__ A_, int lda, int64_t n, const __bf16 *__restrict__ B_, int ldb,
-                                                                  int R, int Nc, void *__restrict__ C_, int ldc, const __bf16 *__restrict__ bias) {
+                                                                  int R, int Nc, void *__restrict__ C_, int ldc, const __bf16 *__restrict__ bias, int accumulate) {
     constexpr int TM = 64 * WM, NTHR = 128 * WM, PA = TM * 4 / NTHR, PB = (128 * 4 + NTHR - 1) / NTHR;
     __shared__ __attribute__((aligned(16))) char lA[2][TM * kGRow], lB[2][128 * kGRow];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
@@ -120,15 +120,16 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3, 4))
                 if (j < n && k < Nc) {
                     const float v = acc[a][b][r] + bv;
                     if constexpr (OUT_BF16) ((__bf16 *)C_)[j * ldc + k] = (__bf16)v;
-                    else ((float *)C_)[j * ldc + k] = v;
+                    else ((float *)C_)[j * ldc + k] = accumulate ? ((const float *)C_)[j * ldc + k] + v : v;   // (C += : fp32 results only)
                 }
             }
         }
 }
 
 int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
-                          const void *bias, hipStream_t stream) {
+                          const void *bias, hipStream_t stream, bool accumulate) {
     if (n <= 0 || Nc <= 0) return MOT_OK;
+    if (accumulate && out_bf16) return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: C += needs an fp32 result");
     if ((R & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A_ & 15) || ((uintptr_t)B_ & 15))
         return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: rows must be 16-byte aligned multiples of 8 elements (R %d, lda %d, ldb %d)", R, lda, ldb);
     const int gy = (Nc + 127) / 128;
@@ -139,10 +140,10 @@ int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, in
     if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: too many rows");
     if (out_bf16)
         hipLaunchKernelGGL((gemm_rows_bf16_kernel<true, WM>), dim3((unsigned)blocks), dim3(128 * WM), 0, stream, (const __bf16 *)A_, lda, n,
-                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias);
+                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, accumulate ? 1 : 0);
     else
         hipLaunchKernelGGL((gemm_rows_bf16_kernel<false, WM>), dim3((unsigned)blocks), dim3(128 * WM), 0, stream, (const __bf16 *)A_, lda, n,
-                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias);
+                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, accumulate ? 1 : 0);
     return check_launch("gemm_rows_bf16_kernel");
 }
 

@@ -152,8 +152,10 @@ size_t char_swa_workspace_bytes(const MotCharSwaDesc &d) {
     const int64_t N = d.n_rows * d.tokens_per_row, slab = N < kSwaSlab ? N : kSwaSlab;
     const size_t hdim = (size_t)d.n_heads * d.head_dim;
     // [cn: char_rows x dim][K, V: char_rows x hdim each][xn | y: slab x max(dim, hdim)][q: slab x hdim][byte_rnorm scratch of the residual call]
-    const size_t fl = swa_align((size_t)d.char_rows * d.dim) + 2 * swa_align((size_t)d.char_rows * hdim) +
-                      swa_align((size_t)slab * (d.dim > (int)hdim ? d.dim : hdim)) + swa_align((size_t)slab * hdim) + swa_align(d.char_rows);
+    size_t fl = swa_align((size_t)d.char_rows * d.dim) + 2 * swa_align((size_t)d.char_rows * hdim) +
+                swa_align((size_t)slab * (d.dim > (int)hdim ? d.dim : hdim)) + swa_align((size_t)slab * hdim) + swa_align(d.char_rows);
+    if (d.matmul_dtype == MOT_BF16)   // bf16 copies: the row operand of a product (xn, then y), wq, wo
+        fl += swa_align(((size_t)slab * (d.dim > (int)hdim ? d.dim : hdim) + 1) / 2) + 2 * swa_align((hdim * (size_t)d.dim + 1) / 2);
     return fl * sizeof(float);
 }
 
@@ -168,8 +170,17 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
     float *xn = vt + swa_align((size_t)d.char_rows * hdim), *yb = xn;   // the attention output reuses the normalised rows' buffer
     float *qb = xn + swa_align((size_t)slab * (d.dim > hdim ? d.dim : hdim));
     float *rn_scratch = qb + swa_align((size_t)slab * hdim);
+    // matmul_dtype == MOT_BF16: the two products over the tokens on the bf16 MFMA (fp32 sums and results), their row operands and
+    // weights narrowed to bf16 first (the weights once per call)
+    const bool mm16 = d.matmul_dtype == MOT_BF16;
+    float *a16 = rn_scratch + swa_align(d.char_rows);
+    float *wq16 = a16 + swa_align(((size_t)slab * (d.dim > hdim ? d.dim : hdim) + 1) / 2), *wo16 = wq16 + swa_align(((size_t)hdim * d.dim + 1) / 2);
     const float eps = d.norm_eps > 0.f ? d.norm_eps : 1e-5f;   // ModelArgs.norm_eps default, inference.py:43
     int rc;
+    if (mm16) {
+        if ((rc = launch_narrow((const float *)d.wq, (int64_t)hdim * d.dim, wq16, stream))) return rc;
+        if ((rc = launch_narrow((const float *)d.wo, (int64_t)hdim * d.dim, wo16, stream))) return rc;
+    }
     // ---- per character-table row: normalise, project to keys and values
     hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int64_t>, dim3((unsigned)((d.char_rows + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream,
                        (const int64_t *)nullptr, (int64_t)d.char_rows, (const float *)d.char_table, (int64_t)d.char_rows, d.dim,
@@ -186,7 +197,10 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
         hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int32_t>, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.tokens + n0, nn,
                            (const float *)d.tok_table, d.tok_rows, d.dim, (const float *)d.attn_norm_w, eps, xn, d.status, kStatusTokenOor);
         if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
-        if ((rc = launch_gemm_rows(xn, d.dim, nn, (const float *)d.wq, d.dim, d.dim, hdim, qb, hdim, true, stream))) return rc;
+        if (mm16) {
+            if ((rc = launch_narrow(xn, nn * d.dim, a16, stream))) return rc;
+            if ((rc = launch_gemm_rows_bf16(a16, d.dim, nn, wq16, d.dim, d.dim, hdim, qb, hdim, false, nullptr, stream))) return rc;
+        } else if ((rc = launch_gemm_rows(xn, d.dim, nn, (const float *)d.wq, d.dim, d.dim, hdim, qb, hdim, true, stream))) return rc;
         // ---- attention
         const int tile = 256;
         const dim3 grid((unsigned)((nn + tile - 1) / tile), (unsigned)d.n_heads);
@@ -224,7 +238,10 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
             if ((rc = launch_embed_mix(r, stream))) return rc;
             accumulate = true;
         }
-        if ((rc = launch_gemm_rows(yb, hdim, nn, (const float *)d.wo, hdim, hdim, d.dim, out, d.dim, true, stream, nullptr, accumulate))) return rc;
+        if (mm16) {
+            if ((rc = launch_narrow(yb, nn * hdim, a16, stream))) return rc;
+            if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, out, d.dim, false, nullptr, stream, accumulate))) return rc;
+        } else if ((rc = launch_gemm_rows(yb, hdim, nn, (const float *)d.wo, hdim, hdim, d.dim, out, d.dim, true, stream, nullptr, accumulate))) return rc;
     }
     return MOT_OK;
 }

@@ -742,10 +742,14 @@ _SWA_VERSIONS = {"no_residual": capi.SWA_NO_RESIDUAL, "one_residual": capi.SWA_O
 def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tensor, char_table: torch.Tensor, *,
              attn_norm_w: torch.Tensor, char_norm_w: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, wo: torch.Tensor,
              n_heads: int, head_dim: int, window: int = 8, norm_eps: float = 1e-5, version: str = "two_residual",
-             lambda_tok: torch.Tensor | None = None, lambda_char: torch.Tensor | None = None) -> torch.Tensor:
+             lambda_tok: torch.Tensor | None = None, lambda_char: torch.Tensor | None = None, matmul: str | None = None) -> torch.Tensor:
     """The Llama character mixer up to the feed-forward (inference.py:146-224 + 260-267 on the gathers of 323-327):
-    tokens (B, T) int, char_ids (B, T, c_v) int64 -> h (B, T, dim) fp32 (bf16 when the tables are bf16: operands widened once, fp32
-    arithmetic, one rounding).  Forward only (the file is the reference's inference path); see mot_char_swa_fwd in include/mot.h."""
+    tokens (B, T) int, char_ids (B, T, c_v) int64 -> h (B, T, dim) fp32.  bf16 tables: bf16 result; operands widened once, the
+    attention in fp32, the two products over the tokens (wq, wo) on the bf16 MFMA with their row operands rounded to bf16
+    (`matmul="fp32"` keeps them on the fp32 MFMA, `matmul="bf16"` asks for the bf16 MFMA with fp32 tables).  Forward only (the
+    file is the reference's inference path); see mot_char_swa_fwd in include/mot.h."""
+    if matmul not in (None, "fp32", "bf16"):
+        raise ValueError(f"char_swa: matmul must be None, 'fp32' or 'bf16' (got {matmul!r})")
     if tokens.ndim == 1:
         tokens, char_ids = tokens[None], char_ids[None]
     if char_ids.ndim != 3 or char_ids.shape[:2] != tokens.shape:
@@ -781,6 +785,8 @@ def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tens
     d.dtype, d.n_rows, d.tokens_per_row = capi.F32, B, T
     d.c_v, d.window, d.n_heads, d.head_dim, d.dim = cid.shape[2], int(window), int(n_heads), int(head_dim), D
     d.version = _SWA_VERSIONS[version]
+    mm_bf16 = (bf and D % 8 == 0 and hdim % 8 == 0) if matmul is None else matmul == "bf16"
+    d.matmul_dtype = capi.BF16 if mm_bf16 else capi.F32
     d.tokens, d.char_ids = capi.ptr(tok), capi.ptr(cid)
     d.tok_table, d.tok_rows, d.char_table, d.char_rows = capi.ptr(tt), tt.shape[0], capi.ptr(ct), ct.shape[0]
     d.norm_eps = float(norm_eps)

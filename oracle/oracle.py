@@ -375,10 +375,12 @@ def _rotary_rotate(t: np.ndarray, rot_dim: int, theta: float = 10000.0) -> np.nd
 
 
 def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, *, n_heads, head_dim, window=8,
-             norm_eps=1e-5, version="two_residual", lambda_tok=1.0, lambda_char=1.0) -> np.ndarray:
+             norm_eps=1e-5, version="two_residual", lambda_tok=1.0, lambda_char=1.0, round_token_products_bf16=False) -> np.ndarray:
     """float64 restatement, line by line, of CustomLlamaModel.forward's gathers (inference.py:323-327) ->
     TokenMixByCharBMMBlock.forward up to `h` (260-267) -> TokenMixByCharBMM.forward (189-238, swa_transform 174-179).
-    tokens (B, T), char_ids (B, T, c_v).  PARITY UNPINNED (see the section header).  numpy, small sizes only."""
+    tokens (B, T), char_ids (B, T, c_v).  PARITY UNPINNED (see the section header).  numpy, small sizes only.
+    round_token_products_bf16: the row operands of the two products over the tokens (the normalised token rows in front of wq,
+    the attention output in front of wo) are rounded to bf16 -- what the HIP path does with matmul_dtype = MOT_BF16."""
     f = np.float64
     tok_table, char_table = np.asarray(tok_table, f), np.asarray(char_table, f)
     toks = tok_table[np.asarray(tokens)]                                   # (b, t, d)        line 323
@@ -386,6 +388,8 @@ def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, 
     rms = lambda x, w: x / np.sqrt((x ** 2).mean(-1, keepdims=True) + norm_eps) * np.asarray(w, f)   # RMSNorm, 126-132
     x, cn = rms(toks, attn_norm_w), rms(chars, char_norm_w)
     b, t, c_v, _ = chars.shape
+    if round_token_products_bf16:
+        x = np.asarray(bf16_round(x), f)
     xq = x @ np.asarray(wq, f).T                                            # (b, t, bmm)      199
     xk, xv = cn @ np.asarray(wk, f).T, cn @ np.asarray(wv, f).T             # (b, t, c_v, bmm) 200
 
@@ -409,6 +413,8 @@ def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, 
     xv = xv.transpose(0, 3, 1, 2, 4)                                        # (b, h, t, nk, dh) 228
     y = np.einsum("bhtk,bhtkd->bhtd", qk, xv)                               # 231-232
     y = y.transpose(0, 2, 1, 3).reshape(b, t, n_heads * head_dim)           # 233
+    if round_token_products_bf16:
+        y = np.asarray(bf16_round(y), f)
     h = y @ np.asarray(wo, f).T                                             # 235
     if version == "one_residual":
         h = h + toks                                                        # 264
