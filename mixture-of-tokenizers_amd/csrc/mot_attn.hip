@@ -170,8 +170,10 @@ static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     L.xkv = take(dual ? T * d.bpt * D : (size_t)L.R * D);   // the (normalised) key/value source rows: per kv position, or per byte-table row
     L.xq = take(D > HD ? T * D : 0);   // the gathered query rows live in y's place until the attention writes y
     const size_t wide = D > HD ? D : HD;
-    L.a16 = take(mm16(d) ? (T * wide + 1) / 2 : 0);   // bf16 copies: the row operand of a product, its weight
-    L.w16 = take(mm16(d) ? (HD * D + 1) / 2 : 0);
+    // bf16 copies: the row operand of a product, its weight (two id tensors: the key / value source rows of every kv position, kv_w)
+    const size_t a16 = dual && T * d.bpt * D > T * wide ? T * d.bpt * D : T * wide;
+    L.a16 = take(mm16(d) ? (a16 + 1) / 2 : 0);
+    L.w16 = take(mm16(d) ? ((dual ? 2 : 1) * HD * D + 1) / 2 : 0);
     L.total = o;
     return L;
 }
@@ -220,8 +222,16 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
                                (int)D, kv_norm, eps, xkv);
             if ((rc = check_launch("rows_norm_kernel"))) return rc;
         }
-        if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w, (int)D, (int)D, (int)HD, kt, (int)HD, true, stream))) return rc;
-        if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w + (size_t)HD * D, (int)D, (int)D, (int)HD, vt, (int)HD, true, stream))) return rc;
+        if (dual && mm16(d)) {   // a row per kv position: these two are 2 bpt times the flops of q -- on the bf16 MFMA like it (xkv is a bf16 tensor in the reference)
+            __bf16 *a16 = (__bf16 *)(ws + L.a16), *w16 = (__bf16 *)(ws + L.w16);
+            if ((rc = launch_narrow(xkv, L.R * D, a16, stream))) return rc;
+            if ((rc = launch_narrow(kv_w, (int64_t)2 * HD * D, w16, stream))) return rc;
+            if ((rc = launch_gemm_rows_bf16(a16, D, L.R, w16, D, D, HD, kt, HD, false, nullptr, stream))) return rc;
+            if ((rc = launch_gemm_rows_bf16(a16, D, L.R, w16 + (size_t)HD * D, D, D, HD, vt, HD, false, nullptr, stream))) return rc;
+        } else {
+            if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w, (int)D, (int)D, (int)HD, kt, (int)HD, true, stream))) return rc;
+            if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w + (size_t)HD * D, (int)D, (int)D, (int)HD, vt, (int)HD, true, stream))) return rc;
+        }
         const int64_t kvw = L.R * H;
         hipLaunchKernelGGL(kv_finish_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kt, vt, L.R, H,
                            d.lambda_factor, eps);
@@ -243,7 +253,8 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
 // ==========================================================================================
 // Backward (loss.backward() through ByteMixinCrossAttn + FlexibleEmbedding, train_gpt.py:1319).  One id tensor; with two
 // (add_padded_and_pulled: xkv = norm?(E[a] + E[b]) per kv position, train_gpt.py:364-372) the "table" below has one row per kv
-// position -- same kernels, identity grouping, and the byte-table gradient comes from the SUM front-end's backward.
+// position -- same kernels, identity grouping, and the byte-table gradient is the norm's backward per position followed by the plain
+// embedding backward once per id tensor.
 //   forward recompute   q_pre = W_q xq;  k_pre, v_pre per byte-table row;  k_n = norm_head(k_pre);  y (attention)
 //   dW_p += g^T y                      gemm_tn            dy = g W_p            dense GEMM (prebuilt k-major operand)
 //   cross_attn_bwd_kernel, one wave per (token, head): softmax weights p_c across lanes (lane c holds key c),
@@ -516,25 +527,44 @@ __global__ __launch_bounds__(kThreads) void kv_norm_kernel(const float *__restri
 __global__ __launch_bounds__(kThreads) void kv_table_bwd_kernel(const float *__restrict__ dkn, const float *__restrict__ dvl, const float *__restrict__ kpre,
                                                                 const float *__restrict__ vpre, int64_t rows, int H, const float *__restrict__ lambda,
                                                                 float eps, float *__restrict__ dkv, float *__restrict__ d_lambda) {
+    // a wave walks (row, head) pairs with the grid's stride and adds its share of d lambda ONCE: with two id tensors there is a pair
+    // per kv position and head (6 M at 65 536 tokens x 16), and one atomic each on the same word took 80 ms
     const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
-    if (w >= rows * H) return;
-    const int64_t row = w / H;
-    const int h = (int)(w - row * H);
     const int HD = H * kHd;
     const float lam = *lambda;
-    const float dv0 = dvl[w * kHd + lane], dv1 = dvl[w * kHd + 64 + lane];
-    const float dl = wave_sum(dv0 * vpre[w * kHd + lane] + dv1 * vpre[w * kHd + 64 + lane]);
+    float dl = 0.f;
+    for (int64_t w = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); w < rows * H; w += (int64_t)gridDim.x * kWaves) {
+        const int64_t row = w / H;
+        const int h = (int)(w - row * H);
+        const float dv0 = dvl[w * kHd + lane], dv1 = dvl[w * kHd + 64 + lane];
+        dl += dv0 * vpre[w * kHd + lane] + dv1 * vpre[w * kHd + 64 + lane];
+        const float k0 = kpre[w * kHd + lane], k1 = kpre[w * kHd + 64 + lane];
+        const float r = rms_scale(wave_sum(k0 * k0 + k1 * k1), kHd, eps);
+        const float kn0 = k0 * r, kn1 = k1 * r, g0 = dkn[w * kHd + lane], g1 = dkn[w * kHd + 64 + lane];
+        const float m = wave_sum(g0 * kn0 + g1 * kn1) / (float)kHd;
+        float *o = dkv + row * 2 * HD + h * kHd;
+        o[lane] = r * (g0 - kn0 * m);
+        o[64 + lane] = r * (g1 - kn1 * m);
+        o[HD + lane] = lam * dv0;
+        o[HD + 64 + lane] = lam * dv1;
+    }
+    dl = wave_sum(dl);
     if (lane == 0 && d_lambda) atomicAdd(d_lambda, dl);
-    const float k0 = kpre[w * kHd + lane], k1 = kpre[w * kHd + 64 + lane];
-    const float r = rms_scale(wave_sum(k0 * k0 + k1 * k1), kHd, eps);
-    const float kn0 = k0 * r, kn1 = k1 * r, g0 = dkn[w * kHd + lane], g1 = dkn[w * kHd + 64 + lane];
-    const float m = wave_sum(g0 * kn0 + g1 * kn1) / (float)kHd;
-    float *o = dkv + row * 2 * HD + h * kHd;
-    o[lane] = r * (g0 - kn0 * m);
-    o[64 + lane] = r * (g1 - kn1 * m);
-    o[HD + lane] = lam * dv0;
-    o[HD + 64 + lane] = lam * dv1;
+}
+
+// two id tensors: dxkv[p] <- norm^T(dxkv[p]) with x = E[a_p] + E[b_p], in place (the gradient of the un-normalised sum, which both
+// table rows receive), one wave per kv position
+__global__ __launch_bounds__(kThreads) void dual_rows_norm_bwd_kernel(const float *__restrict__ table, const int32_t *__restrict__ ids_a,
+                                                                      const int32_t *__restrict__ ids_b, int64_t n, int D, float eps, float *__restrict__ dxn) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6); p < n; p += (int64_t)gridDim.x * kWaves) {
+        const float *ra = table + (int64_t)ids_a[p] * D, *rb = table + (int64_t)ids_b[p] * D;
+        float ss = 0.f, dot = 0.f;
+        for (int j = lane; j < D; j += 64) { const float v = ra[j] + rb[j]; ss += v * v; dot += dxn[p * D + j] * v; }
+        const float rs = rms_scale(wave_sum(ss), D, eps);
+        const float m = wave_sum(dot) * rs / (float)D;      // mean(dxn * xn), xn = x * rs
+        for (int j = lane; j < D; j += 64) dxn[p * D + j] = rs * (dxn[p * D + j] - (ra[j] + rb[j]) * rs * m);
+    }
 }
 
 // xn[row] = norm?(table[row]) for every table row (the operand the K/V GEMMs saw), one wave per row
@@ -579,24 +609,13 @@ __global__ __launch_bounds__(kThreads) void iota_i32_kernel(int32_t *__restrict_
 
 // workspace of the backward, in floats
 struct AttnBwdLayout {
-    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, emb, emb_bytes, b0, b1, w16, total;
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, ids32b, emb, emb_bytes, b0, b1, w16, x16, total;
 };
 static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
     memset(&e, 0, sizeof(e));
     e.struct_size = sizeof(e); e.dtype = MOT_F32; e.n_rows = 1; e.tokens_per_row = n; e.mode = MOT_MIX_NOOP;
     e.tokens = (const int32_t *)tokens; e.tok_table = table; e.tok_rows = rows; e.tok_dim = dim; e.model_dim = dim;
     e.norm_tok = norm; e.eps = eps; e.status = status;
-}
-// the byte-table gradient of the two-id embedding norm?(E[a] + E[b]): the SUM front-end with E as both tables, a as the "token"
-// id, b as the one "byte" id of a D-wide slot
-static void dual_bwd_desc(MotEmbedMixDesc &e, const void *ids_a32, const void *ids_b, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps,
-                          uint32_t *status) {
-    memset(&e, 0, sizeof(e));
-    e.struct_size = sizeof(e); e.dtype = MOT_F32; e.n_rows = 1; e.tokens_per_row = n; e.mode = MOT_MIX_SUM; e.bpt = 1;
-    e.id_source = MOT_IDS_GIVEN; e.ids_a = (const int64_t *)ids_b;
-    e.tokens = (const int32_t *)ids_a32; e.tok_table = table; e.tok_rows = rows; e.tok_dim = dim; e.model_dim = dim;
-    e.byte_table = table; e.byte_rows = rows; e.byte_dim = dim;
-    e.norm_out = norm; e.eps = eps; e.status = status;
 }
 static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     AttnBwdLayout L;
@@ -610,18 +629,21 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     // byte ids of the kv positions, grouped -- or, per position, the identity order (2 P ints)
     L.grp = take(dual ? 2 * P : group_positions_ws_ints((int64_t)P, (int64_t)d.byte_rows));
     L.dkn_tab = take(R * HD); L.dvl_tab = take(R * HD); L.dkv = take(R * 2 * HD); L.xkv = take(R * D); L.dxkv = take(R * D);
-    L.xq = take(T * D); L.dxq = take(T * D); L.ids32 = take(P);
-    MotEmbedMixDesc e;   // scratch of the token-table embedding backward and of the two-id byte-table backward
+    L.xq = take(T * D); L.dxq = take(T * D); L.ids32 = take(P); L.ids32b = take(dual ? P : 0);
+    MotEmbedMixDesc e;   // scratch of the token-table embedding backward and of the two byte-table backwards of the two-id embedding
     noop_bwd_desc(e, nullptr, (int64_t)T, nullptr, d.tok_rows, (int)D, d.norm_tok, 0.f, nullptr);
     size_t a = embed_mix_bwd_workspace_bytes(e), b = 0;
     if (dual) {
-        dual_bwd_desc(e, nullptr, nullptr, (int64_t)P, nullptr, d.byte_rows, (int)D, d.norm_byte, 0.f, nullptr);
+        noop_bwd_desc(e, nullptr, (int64_t)P, nullptr, d.byte_rows, (int)D, 0, 0.f, nullptr);
         b = embed_mix_bwd_workspace_bytes(e);
     }
     L.emb_bytes = a > b ? a : b;
     L.emb = take((L.emb_bytes + 3) / 4);
     const size_t wide = D > HD ? D : HD;   // matmul_dtype == MOT_BF16: two bf16 row operands and one (transposed) weight at a time
-    L.b0 = take(mm16(d) ? (T * wide + 1) / 2 : 0); L.b1 = take(mm16(d) ? (T * wide + 1) / 2 : 0); L.w16 = take(mm16(d) ? (HD * D + 1) / 2 : 0);
+    // (two id tensors: + the key / value source rows of every kv position; b1 also takes dkv, w16 also kv_w)
+    const size_t b1n = dual && P * 2 * HD > T * wide ? P * 2 * HD : T * wide;
+    L.b0 = take(mm16(d) ? (T * wide + 1) / 2 : 0); L.b1 = take(mm16(d) ? (b1n + 1) / 2 : 0); L.w16 = take(mm16(d) ? ((dual ? 2 : 1) * HD * D + 1) / 2 : 0);
+    L.x16 = take(mm16(d) && dual ? (P * D + 1) / 2 : 0);
     L.total = o;
     return L;
 }
@@ -676,8 +698,18 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         hipLaunchKernelGGL(rows_norm_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, R, D, d.norm_byte, eps, xkv);
         if ((rc = check_launch("rows_norm_kernel"))) return rc;
     }
-    if ((rc = launch_gemm_rows(xkv, D, R, kv_w, D, D, HD, kpre, HD, true, stream))) return rc;
-    if ((rc = launch_gemm_rows(xkv, D, R, kv_w + (size_t)HD * D, D, D, HD, vpre, HD, true, stream))) return rc;
+    const bool kv16 = dual && mm16(d);   // the products over the kv positions on the bf16 MFMA too (forward: launch_cross_attn)
+    __bf16 *x16 = (__bf16 *)(ws + L.x16);
+    if (kv16) {
+        __bf16 *w16k = (__bf16 *)(ws + L.w16);
+        if ((rc = launch_narrow(xkv, R * D, x16, stream))) return rc;
+        if ((rc = launch_narrow(kv_w, (int64_t)2 * HD * D, w16k, stream))) return rc;
+        if ((rc = launch_gemm_rows_bf16(x16, D, R, w16k, D, D, HD, kpre, HD, false, nullptr, stream))) return rc;
+        if ((rc = launch_gemm_rows_bf16(x16, D, R, w16k + (size_t)HD * D, D, D, HD, vpre, HD, false, nullptr, stream))) return rc;
+    } else {
+        if ((rc = launch_gemm_rows(xkv, D, R, kv_w, D, D, HD, kpre, HD, true, stream))) return rc;
+        if ((rc = launch_gemm_rows(xkv, D, R, kv_w + (size_t)HD * D, D, D, HD, vpre, HD, true, stream))) return rc;
+    }
     const int64_t kvw = R * H;
     hipLaunchKernelGGL(kv_norm_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kpre, vpre, R, H, d.lambda_factor, eps, kn, vl);
     if ((rc = check_launch("kv_norm_kernel"))) return rc;
@@ -742,19 +774,44 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     MotEmbedMixGrads eg;
     memset(&eg, 0, sizeof(eg));
     eg.struct_size = sizeof(eg);
-    hipLaunchKernelGGL(kv_table_bwd_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, dkn_tab, dvl_tab, kpre, vpre, R, H,
-                       d.lambda_factor, eps, dkv, gr.d_lambda);
+    {
+        int64_t nb = (kvw + kWaves - 1) / kWaves;
+        if (nb > 8192) nb = 8192;
+        hipLaunchKernelGGL(kv_table_bwd_kernel, dim3((unsigned)nb), dim3(kThreads), 0, stream, dkn_tab, dvl_tab, kpre, vpre, R, H, d.lambda_factor, eps, dkv,
+                           gr.d_lambda);
+    }
     if ((rc = check_launch("kv_table_bwd_kernel"))) return rc;
     // ---- kv_w and the byte table (xkv: the normalised table rows built for the recompute above)
-    if (gr.d_kv_w && (rc = launch_gemm_tn(dkv, 2 * HD, 2 * HD, xkv, D, D, R, (float *)gr.d_kv_w, D, stream))) return rc;
+    if (kv16 && (gr.d_kv_w || gr.d_byte_table) && (rc = launch_narrow(dkv, R * 2 * HD, b1, stream))) return rc;
+    if (gr.d_kv_w) {
+        if (kv16) rc = launch_gemm_tn_bf16(b1, 2 * HD, 2 * HD, x16, D, D, R, (float *)gr.d_kv_w, D, stream);
+        else rc = launch_gemm_tn(dkv, 2 * HD, 2 * HD, xkv, D, D, R, (float *)gr.d_kv_w, D, stream);
+        if (rc) return rc;
+    }
     if (gr.d_byte_table && dual) {
-        // d(E[a] + E[b]) = norm^T(dxkv), added to the table at rows a and b: the SUM front-end's backward with the byte table in
-        // both roles (its token-table and byte-table gradients are the same buffer; both are accumulated with atomic adds)
-        if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;
-        dual_bwd_desc(ed, ids32, d.ids_b, P, d.byte_table, d.byte_rows, D, d.norm_byte, eps, d.status);
-        ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
-        eg.grad_out = dxkv; eg.d_tok_table = gr.d_byte_table; eg.d_byte_table = gr.d_byte_table;
-        if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
+        // d(E[a] + E[b]) = norm^T(dxkv), added to the table at rows a AND b: the norm's backward in place, then the plain embedding
+        // backward twice (positions grouped by id, run sums, one row add per run and wave).  (Round 2 used the SUM front-end's
+        // backward with the table in both roles: its byte side is built for narrow byte rows in LDS, and a 768-wide "byte" row per
+        // position became 800 M float atomics on 458 rows -- 226 ms of the 418 this backward took at 65 536 tokens x 16.)
+        if (kv16) {
+            if ((rc = launch_narrow_transpose(kv_w, 2 * HD, D, w16, stream))) return rc;   // [D][2 HD]
+            if ((rc = launch_gemm_rows_bf16(b1, 2 * HD, R, w16, 2 * HD, 2 * HD, D, dxkv, D, false, nullptr, stream))) return rc;
+        } else if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;
+        int32_t *ids32b = (int32_t *)(ws + L.ids32b);
+        hipLaunchKernelGGL(ids_to_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, d.ids_b, P, (int64_t)d.byte_rows, ids32b);
+        if ((rc = check_launch("ids_to_i32"))) return rc;
+        if (d.norm_byte) {
+            hipLaunchKernelGGL(dual_rows_norm_bwd_kernel, dim3(8192), dim3(kThreads), 0, stream, (const float *)d.byte_table, ids32, ids32b, P, D, eps, dxkv);
+            if ((rc = check_launch("dual_rows_norm_bwd_kernel"))) return rc;
+        }
+        for (const int32_t *ids : {(const int32_t *)ids32, (const int32_t *)ids32b}) {
+            noop_bwd_desc(ed, ids, P, d.byte_table, d.byte_rows, D, 0, eps, d.status);
+            ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;
+            memset(&eg, 0, sizeof(eg));
+            eg.struct_size = sizeof(eg);
+            eg.grad_out = dxkv; eg.d_tok_table = gr.d_byte_table;
+            if ((rc = launch_embed_mix_bwd(ed, eg, stream))) return rc;
+        }
         memset(&eg, 0, sizeof(eg));
         eg.struct_size = sizeof(eg);
     } else if (gr.d_byte_table) {

@@ -376,6 +376,42 @@ def test_digit_cross_attn_errors(mot):
             net(toks)
 
 
+def test_cross_attn_bf16_tables_two_id_tensors(mot):
+    """bf16 tables with the add_padded_and_pulled embedding (train_gpt.py:364-372): a key / value row per kv position, so the K / V
+    projections, dW_kv and dxkv are products over T * bpt rows and run on the bf16 MFMA with the rest (xkv, dkv rounded to bf16).
+    Float64 oracle on the bf16-valued operands, without those roundings: forward within four bf16 steps of the larger of the
+    output and the outputs' rms, gradients within 1 % of each tensor's largest entry."""
+    from mixture_of_tokenizers_amd.modules import Rotary
+    D, bpt, Vt, T, seed = 256, 8, 512, 96, 9983
+    H = D // 128
+    tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=4.0)
+    toks = gi.fineweb_like_tokens(seed, 1, T, vocab=Vt, eot_p=0.01)
+    Et, Eb = orc.bf16_round(gi.normal_table(seed + 2, Vt, D)), orc.bf16_round(gi.normal_table(seed + 3, gi.BYTE_VOCAB, D))
+    q_w, kv_w, p_w = (f32(a) for a in gi.cross_weights(seed + 4, D))
+    padded = orc.tokens_to_bytes(toks, tab.astype(np.float32))
+    pulled = orc.pull_from_left(padded, bpt, gi.PAD, gi.EOT)
+    g = orc.bf16_round(np.random.RandomState(seed + 5).standard_normal((1, T, D)))
+    rq, rk = Rotary(128, T), Rotary(128, T * bpt)
+    rot = [rq.cos, rq.sin, rk.cos, rk.sin]
+    d64 = lambda a: np.asarray(a, dtype=np.float64)
+    used = lambda w: d64(orc.bf16_round(w))
+    lam = float(orc.bf16_round(np.array([0.35]))[0])
+    args = (toks[0], padded[0], pulled[0], d64(Et), d64(Eb), used(q_w), used(kv_w), used(p_w), lam, *[r.numpy() for r in rot])
+    ref = orc.cross_attn(*args, bpt=bpt, n_heads=H, dtype=np.float64, head_layout=0)
+    refg = orc.cross_attn_bwd(*args, d64(g), bpt=bpt, n_heads=H, norm_tok=True, norm_byte=True, head_layout=0)
+    P = lambda a, dt=None: torch.nn.Parameter(dev(a) if dt is None else dev(a).to(dt))
+    pEt, pEb = P(Et, torch.bfloat16), P(Eb, torch.bfloat16)
+    pq, pkv, pp, plam = P(q_w), P(kv_w), P(p_w), torch.nn.Parameter(torch.tensor(0.35, device=DEV))
+    x = mot.functional.cross_attn(dev(toks), dev(padded), pEt, pEb, q_w=pq, kv_w=pkv, proj_w=pp, lambda_factor=plam, ids_b=dev(pulled),
+                                  cos_q=rot[0].to(DEV), sin_q=rot[1].to(DEV), cos_k=rot[2].to(DEV), sin_k=rot[3].to(DEV), bpt=bpt, n_heads=H)
+    got, want = host(x.float())[0].astype(np.float64), d64(ref)
+    assert (np.abs(got - want) <= 4 * 2.0 ** -7 * np.maximum(np.abs(want), np.sqrt((want ** 2).mean()))).all()
+    (x.float() * dev(g)).sum().backward()
+    mot.check_status()
+    for p, key in ((pEt, "tok_table"), (pEb, "byte_table"), (pq, "q_w"), (pkv, "kv_w"), (pp, "proj_w")):
+        assert grel(host(p.grad.float()), refg[key]) < 1e-2, key
+
+
 @pytest.mark.parametrize("matmul", [None, "fp32"])
 def test_cross_attn_bf16_tables(mot, matmul):
     """The production cast (train_gpt.py:1124-1126: nn.Embedding -> bfloat16; the attention weights stay fp32 masters and are cast
