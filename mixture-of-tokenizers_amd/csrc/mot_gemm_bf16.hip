@@ -8,6 +8,8 @@
 // Used by the composed bf16 concat + linear forward (mot_linear.hip) -- the fused tile kernel of mot_linear_bf16.hip spends
 // its time gathering and staging, not multiplying.
 #include <type_traits>
+#include <atomic>
+#include <stdlib.h>
 
 #include "mot_internal.hpp"
 #include "mot_tile.hpp"
@@ -126,12 +128,163 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3, 4))
         }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------------------
+// Round 3: 256 x 256 output blocks, both operands by LDS-DMA, one barrier per step.  The 128 x 128 kernel above stages through
+// registers, re-reads every fragment per 2 MFMAs and reaches 23-25 % of the bf16 MFMA peak; since round 3 it also carries the
+// cross-attention mixin's and the character mixer's products.  Here
+//   * 8 waves as 2 x 4, a wave 128 x 64 = 4 x 2 tiles of 32 x 32 (128 accumulator registers): a fragment of A feeds 2 MFMAs, one of
+//     B feeds 4 -- 12 fragment reads per 16 MFMAs and step;
+//   * both operands arrive by global_load_lds (16 bytes per lane, no staging registers) into FOUR stages of 32 reduction indices
+//     (2 x 16 KB each), XOR-swizzled on the source side exactly as the W stages of mot_concat16.hip (piece p of stage row q at
+//     q * 64 + ((p ^ (q >> 2)) & 3) * 16: conflict-free ds_read_b128 fragments), requested THREE steps ahead;
+//   * the barrier in front of step s guarantees stage s + 1 as well, so the fragments of a step's second k-block are read during
+//     its first and those of the next step's first k-block during its second: when the barrier opens, the operands of the next
+//     eight MFMAs are in registers, and every LDS wait sits behind eight MFMAs.  One barrier per step; nothing serial behind it.
+// LDS reads and waits are inline asm for the reason given in mot_concat16.hip (hipcc drains the DMA in front of its own LDS reads).
+// Shapes: Nc a multiple of 256, R a multiple of 32, rows 16-byte aligned; the launcher falls back to the kernel above otherwise.
+#pragma clang diagnostic ignored "-Wunused-lambda-capture"
+#define G256_FRAG(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+typedef int i32x4g __attribute__((ext_vector_type(4)));
+constexpr int kG2Threads = 512, kG2Stage = 2 * 256 * 64, kG2NS = 4, kG2PD = 3;
+template <bool OUT_BF16>
+__global__ __launch_bounds__(kG2Threads) void gemm_rows_bf16_256_kernel(const __bf16 *__restrict__ A_, int lda, int64_t n, const __bf16 *__restrict__ B_, int ldb,
+                                                                        int R, int Nc, void *__restrict__ C_, int ldc, const __bf16 *__restrict__ bias, int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) char lds_g2[];   // [4 stages][A: 256 rows x 64 B | B: 256 rows x 64 B]
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
+    const int64_t gx = (n + 255) / 256;
+    const int gy = Nc / 256;
+    const int64_t id = blockIdx.x, seq = id >> 3;
+    const int64_t panel = (seq / gy) * 8 + (id & 7);   // (the XCD-aware order of the kernel above)
+    if (panel >= gx) return;
+    const int64_t j0 = panel * 256;
+    const int k0 = (int)(seq % gy) * 256;
+    const uint32_t oS = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)lds_g2;
+    // DMA: wave-instruction j writes stage rows 16 j .. 16 j + 15 (1 KiB); this wave: j = 2 wave, 2 wave + 1 of A and of B
+    uint32_t goffA[2], goffB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = (2 * wave + i) * 16 + (lane >> 2), pc = ((lane & 3) ^ (q >> 2)) & 3;
+        const int64_t ra = min(j0 + q, n - 1) - j0;   // rows past the end repeat the last one (computed, never stored)
+        goffA[i] = (uint32_t)((ra * lda + 8 * pc) * 2);
+        goffB[i] = (uint32_t)(((int64_t)q * ldb + 8 * pc) * 2);
+    }
+    const char *Ab = (const char *)(A_ + j0 * lda), *Bb = (const char *)(B_ + (int64_t)k0 * ldb);
+    const int nsteps = R / 32;
+    auto dma = [&](int s, auto ic) {   // (a step past the end re-reads the last one into a stage nobody reads)
+        constexpr int i = decltype(ic)::value;   // 0, 1: A; 2, 3: B
+        char *st = lds_g2 + (s % kG2NS) * kG2Stage + (i >= 2 ? 256 * 64 : 0) + (2 * wave + (i & 1)) * 1024;
+        const uint32_t ko = 64u * (uint32_t)min(s, nsteps - 1);
+        const char *g = i >= 2 ? Bb + (goffB[i & 1] + ko) : Ab + (goffA[i & 1] + ko);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)st, 16, 0, 0);
+    };
+    auto dma_all = [&](int s) {
+        dma(s, std::integral_constant<int, 0>{}); dma(s, std::integral_constant<int, 1>{});
+        dma(s, std::integral_constant<int, 2>{}); dma(s, std::integral_constant<int, 3>{});
+    };
+    dma_all(0); dma_all(1); dma_all(2);
+    f32x16g acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // fragment addresses inside a stage: row = (wm | wn) + 32 t + li, piece (2 kk + h) ^ (row >> 2): t adds t * 2048, kk flips bit 5
+    const uint32_t fa0 = oS + (wm + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
+    const uint32_t fb0 = oS + 256 * 64 + (wn + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
+    i32x4g fA[2][4], fB[2][2];   // [k-block][tile]
+    auto frags = [&, &fA = fA, &fB = fB](auto kkc, int s) {   // (explicit captures: clang wants them for asm operands in generic lambdas)
+        constexpr int kk = decltype(kkc)::value;
+        const uint32_t so = (uint32_t)(s % kG2NS) * kG2Stage;
+        const uint32_t pa = (fa0 + so) ^ (kk * 32), pb = (fb0 + so) ^ (kk * 32);
+        G256_FRAG(fB[kk][0], pb, 0); G256_FRAG(fB[kk][1], pb, 2048);
+        G256_FRAG(fA[kk][0], pa, 0); G256_FRAG(fA[kk][1], pa, 2048); G256_FRAG(fA[kk][2], pa, 4096); G256_FRAG(fA[kk][3], pa, 6144);
+    };
+    auto mfmas = [&, &fA = fA, &fB = fB](auto kkc) {
+        constexpr int kk = decltype(kkc)::value;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, fA[kk][a]), __builtin_bit_cast(bf16x8g, fB[kk][b]), acc[a][b], 0, 0, 0);
+    };
+    using K0 = std::integral_constant<int, 0>;
+    using K1 = std::integral_constant<int, 1>;
+    // stage 0 for everyone, then the first k-block of step 0 into registers
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    frags(K0{}, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        // this wave's share of stage s + 1 has landed (younger: stage s + 2); the fragments requested in the previous step too
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)"
+                     : "+v"(fA[0][0]), "+v"(fA[0][1]), "+v"(fA[0][2]), "+v"(fA[0][3]), "+v"(fB[0][0]), "+v"(fB[0][1])
+                     :
+                     : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        frags(K1{}, s);              // second k-block of this step: stage s is complete since the previous barrier
+        dma_all(s + kG2PD);          // into the stage read in step s - 1: everyone is past it
+        mfmas(K0{});
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(fA[1][0]), "+v"(fA[1][1]), "+v"(fA[1][2]), "+v"(fA[1][3]), "+v"(fB[1][0]), "+v"(fB[1][1])
+                     :
+                     : "memory");
+        frags(K0{}, s + 1);          // first k-block of the next step: stage s + 1 is complete since this step's barrier
+        mfmas(K1{});
+    }
+    // (what was requested past the last step is still on its way: hold the registers and the stages until it has landed)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                 : "+v"(fA[0][0]), "+v"(fA[0][1]), "+v"(fA[0][2]), "+v"(fA[0][3]), "+v"(fB[0][0]), "+v"(fB[0][1])
+                 :
+                 : "memory");
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); A is the row operand
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int k = k0 + wn + b * 32 + li;
+            const float bv = bias ? (float)bias[k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t j = j0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (j < n) {
+                    const float v = acc[a][b][r] + bv;
+                    if constexpr (OUT_BF16) ((__bf16 *)C_)[j * ldc + k] = (__bf16)v;
+                    else ((float *)C_)[j * ldc + k] = accumulate ? ((const float *)C_)[j * ldc + k] + v : v;
+                }
+            }
+        }
+}
+
 int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
                           const void *bias, hipStream_t stream, bool accumulate) {
     if (n <= 0 || Nc <= 0) return MOT_OK;
     if (accumulate && out_bf16) return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: C += needs an fp32 result");
     if ((R & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A_ & 15) || ((uintptr_t)B_ & 15))
         return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: rows must be 16-byte aligned multiples of 8 elements (R %d, lda %d, ldb %d)", R, lda, ldb);
+    bool big = (Nc % 256) == 0 && (R % 32) == 0 && n >= 512 && (int64_t)256 * (lda > ldb ? lda : ldb) * 2 < 0x7fffffffLL;
+#ifdef MOT_DEV_ABLATION
+    if (getenv("MOT_GEMM16_OLD")) big = false;
+#endif
+    if (big) {   // 256 x 256 blocks by LDS-DMA
+        const int64_t gx2 = (n + 255) / 256, blocks2 = (gx2 + 7) / 8 * 8 * (Nc / 256);
+        if (blocks2 > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: too many rows");
+        const size_t lds = (size_t)kG2NS * kG2Stage;
+        static std::atomic<uint64_t> ok0{0}, ok1{0};
+        if (out_bf16) {
+            if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_bf16_256_kernel<true>, ok1, "gemm_rows_bf16_256_kernel")) return rc;
+            hipLaunchKernelGGL((gemm_rows_bf16_256_kernel<true>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
+                               (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, 0);
+        } else {
+            if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_bf16_256_kernel<false>, ok0, "gemm_rows_bf16_256_kernel")) return rc;
+            hipLaunchKernelGGL((gemm_rows_bf16_256_kernel<false>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
+                               (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, accumulate ? 1 : 0);
+        }
+        return check_launch("gemm_rows_bf16_256_kernel");
+    }
     const int gy = (Nc + 127) / 128;
     // (WM = 4, 256-row blocks on 8 waves, halves the reads of W per output but measured 3-7 % slower at 65 536 x 768 x 768)
     constexpr int WM = 2, TM = 64 * WM;

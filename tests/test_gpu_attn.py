@@ -412,8 +412,8 @@ def test_cross_attn_bf16_tables_two_id_tensors(mot):
         assert grel(host(p.grad.float()), refg[key]) < 1e-2, key
 
 
-@pytest.mark.parametrize("matmul", [None, "fp32"])
-def test_cross_attn_bf16_tables(mot, matmul):
+@pytest.mark.parametrize("matmul,T", [(None, 120), ("fp32", 120), (None, 1100)])   # (1100 rows: the 256 x 256 bf16 product kernel, last block partial)
+def test_cross_attn_bf16_tables(mot, matmul, T):
     """The production cast (train_gpt.py:1124-1126: nn.Embedding -> bfloat16; the attention weights stay fp32 masters and are cast
     where they are used, lines 277-278): bf16 tables go in, a bf16 result and bf16 table gradients come out.  The attention
     kernels are fp32 -- operands are widened once per call -- and the checker is the float64 oracle on the bf16-VALUED operands
@@ -422,11 +422,11 @@ def test_cross_attn_bf16_tables(mot, matmul):
     matmul=None (what bf16 tables select): q, c_proj and their backward products on the bf16 MFMA, their row operands rounded to
     bf16 where the reference's are bf16 tensors (xq out of norm(), y out of the attention).  The oracle is run with exactly those
     two roundings (the normalised token rows rounded and handed in as a T-row table, the attention output taken through an
-    identity c_proj, rounded, and projected in float64): same bar against that; against the un-rounded evaluation the two
-    extra roundings cost up to three more steps on the smallest outputs (measured 3.5; bar 4, rms under one step).  Gradients: within 1 % of each tensor's largest entry either way (bf16 gradients of
+    identity c_proj, rounded, and projected in float64): same bar against that; against the un-rounded evaluation: three steps
+    of the larger of the output and the outputs' rms, rms error under one step.  Gradients: within 1 % of each tensor's largest entry either way (bf16 gradients of
     the tables carry 2^-8 of rounding, the bf16 products 2^-9 per operand)."""
     from mixture_of_tokenizers_amd.modules import Rotary
-    D, bpt, Vt, T, seed = 256, 8, 512, 120, 9981
+    D, bpt, Vt, seed = 256, 8, 512, 9981
     H = D // 128
     tab = gi.synth_ttb(seed + 1, Vt, bpt, "left", mean_valid=4.0)
     toks = gi.fineweb_like_tokens(seed, 1, T, vocab=Vt, eot_p=0.01)
@@ -462,7 +462,8 @@ def test_cross_attn_bf16_tables(mot, matmul):
                            dtype=np.float64, head_layout=0, norm_tok=False)
         emul = orc.bf16_round(d64(orc.bf16_round(y)) @ used(p_w).T)
         assert (steps(emul) <= 1).all() and (got == emul).mean() > 0.97, (steps(emul).max(), (got == emul).mean())
-        assert (steps(want) <= 4).all() and np.sqrt((steps(want) ** 2).mean()) < 1.0, (steps(want).max(), np.sqrt((steps(want) ** 2).mean()))
+        # (without the two roundings: they move an output by ~2^-9 of the TYPICAL size of the outputs, whatever its own size)
+        assert (np.abs(got - want) <= 3 * 2.0 ** -7 * np.maximum(np.abs(want), np.sqrt((want ** 2).mean()))).all() and np.sqrt((steps(want) ** 2).mean()) < 1.0
     (x.float() * dev(g)).sum().backward()
     mot.check_status()
     assert pEt.grad.dtype == torch.bfloat16 and pEb.grad.dtype == torch.bfloat16 and pq.grad.dtype == torch.float32
