@@ -238,11 +238,12 @@ def test_cross_attn_kv_table_cache(mot):
         assert not torch.equal(c, d)
 
 
-def test_cross_attn_forward_is_capturable_in_a_hip_graph(mot):
+@pytest.mark.parametrize("T,matmul", [(200, None), (700, "bf16")])   # (bf16: narrowing kernels + the 256 x 256 product kernel in the graph)
+def test_cross_attn_forward_is_capturable_in_a_hip_graph(mot, T, matmul):
     """The mixin forward is a fixed sequence of kernels on the given stream (seam gather, dense products, table kernels, attention):
     capture it, change tokens, ids and a weight in place, replay, compare with an eager call."""
     from mixture_of_tokenizers_amd.modules import Rotary
-    D, bpt, Vt, T, H = 256, 8, 500, 200, 2
+    D, bpt, Vt, H = 256, 8, 500, 2
     rs = np.random.RandomState(9981)
     toks = dev(rs.randint(0, Vt, (1, T)).astype(np.int32))
     ids = dev(rs.randint(0, gi.BYTE_VOCAB, (1, T * bpt)).astype(np.int64))
@@ -250,7 +251,7 @@ def test_cross_attn_forward_is_capturable_in_a_hip_graph(mot):
     q_w, kv_w, p_w = (dev(f32(a)) for a in gi.cross_weights(9984, D))
     rq, rk = Rotary(128, T), Rotary(128, T * bpt)
     kw = dict(q_w=q_w, kv_w=kv_w, proj_w=p_w, lambda_factor=torch.tensor(0.6, device=DEV), cos_q=rq.cos.to(DEV), sin_q=rq.sin.to(DEV),
-              cos_k=rk.cos.to(DEV), sin_k=rk.sin.to(DEV), bpt=bpt, n_heads=H)
+              cos_k=rk.cos.to(DEV), sin_k=rk.sin.to(DEV), bpt=bpt, n_heads=H, matmul=matmul)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s), torch.no_grad():
