@@ -2010,6 +2010,8 @@ constexpr int kGemmRowsPass = 1 << 30;
 int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed,
                      hipStream_t stream, const float *bias, bool accumulate) {
     if (n <= 0 || Nc <= 0) return MOT_OK;
+    if (b_transposed && R > 0 && gemm_rows_f32_256_usable(A_, lda, n, B_, ldb, R, Nc))   // 256 x 256 blocks by LDS-DMA (mot_gemm_bf16.hip)
+        return launch_gemm_rows_f32_256(A_, lda, n, B_, ldb, R, Nc, C, ldc, bias, accumulate, stream);
     const int64_t gx = (n + 127) / 128;
     const int gy = (Nc + 127) / 128;
     const int64_t blocks = (gx + 7) / 8 * 8 * gy;   // 1-D, see the block order in the kernel

@@ -145,118 +145,192 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3, 4))
 #pragma clang diagnostic ignored "-Wunused-lambda-capture"
 #define G256_FRAG(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 typedef int i32x4g __attribute__((ext_vector_type(4)));
-constexpr int kG2Threads = 512, kG2Stage = 2 * 256 * 64, kG2NS = 4, kG2PD = 3;
-template <bool OUT_BF16>
-__global__ __launch_bounds__(kG2Threads) void gemm_rows_bf16_256_kernel(const __bf16 *__restrict__ A_, int lda, int64_t n, const __bf16 *__restrict__ B_, int ldb,
-                                                                        int R, int Nc, void *__restrict__ C_, int ldc, const __bf16 *__restrict__ bias, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) char lds_g2[];   // [4 stages][A: 256 rows x 64 B | B: 256 rows x 64 B]
+constexpr int kG2Threads = 512, kG2NS = 4, kG2PD = 3;
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_g(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for_g<I + 1, N>(f);
+    }
+}
+// E = float: the same kernel on v_mfma_f32_32x32x2f32 -- a stage row is again 64 bytes, now 16 reduction indices, and a lane's
+// 16-byte fragment holds the k of FOUR MFMAs (lanes 0-31 take piece 2 kk, lanes 32-63 piece 2 kk + 1, so the MFMA that uses
+// register e of the fragment contracts k = 8 kk + e and 8 kk + 4 + e: any pairing serves as long as both operands use it).
+// A 64-cycle MFMA leaves the LDS pipe idle whatever the tile, so the fp32 form takes 64 x 64 per wave (8 waves as 4 x 2: 256 x 128
+// per workgroup) and spends the registers on a second accumulator set: `acc` collects 8 steps (128 products), then is folded into
+// `sum` with vector adds -- blocked summation like the 128 x 128 kernel of mot_backward.hip and the reference's BLAS, which the
+// concat parity bar (twice the reference's own fp32 error) needs at K = 768.
+template <typename E, bool OUT_BF16, int MT, int NT, int WC>
+__global__ __launch_bounds__(kG2Threads) void gemm_rows_256_kernel(const E *__restrict__ A_, int lda, int64_t n, const E *__restrict__ B_, int ldb,
+                                                                   int R, int Nc, void *__restrict__ C_, int ldc, const E *__restrict__ bias, int accumulate) {
+    constexpr int EPR = 64 / (int)sizeof(E), EPP = 16 / (int)sizeof(E);   // elements per stage row / per 16-byte piece
+    constexpr int BM = (8 / WC) * 32 * MT, BN = WC * 32 * NT, kStage = (BM + BN) * 64, NA = BM / 128, NB = BN / 128, ND = NA + NB;
+    constexpr bool kFoldSums = std::is_same_v<E, float>;
+    extern __shared__ __attribute__((aligned(16))) char lds_g2[];   // [4 stages][A: BM rows x 64 B | B: BN rows x 64 B]
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;
-    const int64_t gx = (n + 255) / 256;
-    const int gy = Nc / 256;
+    const int wm = (wave / WC) * 32 * MT, wn = (wave % WC) * 32 * NT;
+    const int64_t gx = (n + BM - 1) / BM;
+    const int gy = Nc / BN;
     const int64_t id = blockIdx.x, seq = id >> 3;
     const int64_t panel = (seq / gy) * 8 + (id & 7);   // (the XCD-aware order of the kernel above)
     if (panel >= gx) return;
-    const int64_t j0 = panel * 256;
-    const int k0 = (int)(seq % gy) * 256;
+    const int64_t j0 = panel * BM;
+    const int k0 = (int)(seq % gy) * BN;
     const uint32_t oS = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char *)lds_g2;
-    // DMA: wave-instruction j writes stage rows 16 j .. 16 j + 15 (1 KiB); this wave: j = 2 wave, 2 wave + 1 of A and of B
-    uint32_t goffA[2], goffB[2];
+    // DMA: wave-instruction j writes stage rows 16 j .. 16 j + 15 (1 KiB); this wave: j = NA wave + i of A, NB wave + i of B
+    uint32_t goffA[NA], goffB[NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int q = (2 * wave + i) * 16 + (lane >> 2), pc = ((lane & 3) ^ (q >> 2)) & 3;
+    for (int i = 0; i < NA; ++i) {
+        const int q = (NA * wave + i) * 16 + (lane >> 2), pc = ((lane & 3) ^ (q >> 2)) & 3;
         const int64_t ra = min(j0 + q, n - 1) - j0;   // rows past the end repeat the last one (computed, never stored)
-        goffA[i] = (uint32_t)((ra * lda + 8 * pc) * 2);
-        goffB[i] = (uint32_t)(((int64_t)q * ldb + 8 * pc) * 2);
+        goffA[i] = (uint32_t)((ra * lda + EPP * pc) * sizeof(E));
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int q = (NB * wave + i) * 16 + (lane >> 2), pc = ((lane & 3) ^ (q >> 2)) & 3;
+        goffB[i] = (uint32_t)(((int64_t)q * ldb + EPP * pc) * sizeof(E));
     }
     const char *Ab = (const char *)(A_ + j0 * lda), *Bb = (const char *)(B_ + (int64_t)k0 * ldb);
-    const int nsteps = R / 32;
-    auto dma = [&](int s, auto ic) {   // (a step past the end re-reads the last one into a stage nobody reads)
-        constexpr int i = decltype(ic)::value;   // 0, 1: A; 2, 3: B
-        char *st = lds_g2 + (s % kG2NS) * kG2Stage + (i >= 2 ? 256 * 64 : 0) + (2 * wave + (i & 1)) * 1024;
+    const int nsteps = R / EPR;
+    auto dma_all = [&](int s) {   // (a step past the end re-reads the last one into a stage nobody reads)
+        char *st = lds_g2 + (s % kG2NS) * kStage;
         const uint32_t ko = 64u * (uint32_t)min(s, nsteps - 1);
-        const char *g = i >= 2 ? Bb + (goffB[i & 1] + ko) : Ab + (goffA[i & 1] + ko);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g, (__attribute__((address_space(3))) void *)st, 16, 0, 0);
-    };
-    auto dma_all = [&](int s) {
-        dma(s, std::integral_constant<int, 0>{}); dma(s, std::integral_constant<int, 1>{});
-        dma(s, std::integral_constant<int, 2>{}); dma(s, std::integral_constant<int, 3>{});
+        static_for_g<0, NA>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ab + (goffA[i] + ko)),
+                                             (__attribute__((address_space(3))) void *)(st + (NA * wave + i) * 1024), 16, 0, 0);
+        });
+        static_for_g<0, NB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Bb + (goffB[i] + ko)),
+                                             (__attribute__((address_space(3))) void *)(st + BM * 64 + (NB * wave + i) * 1024), 16, 0, 0);
+        });
     };
     dma_all(0); dma_all(1); dma_all(2);
-    f32x16g acc[4][2];
+    f32x16g acc[MT][NT], sum[kFoldSums ? MT : 1][kFoldSums ? NT : 1];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                acc[a][b][r] = 0.f;
+                if constexpr (kFoldSums) sum[a][b][r] = 0.f;
+            }
     // fragment addresses inside a stage: row = (wm | wn) + 32 t + li, piece (2 kk + h) ^ (row >> 2): t adds t * 2048, kk flips bit 5
     const uint32_t fa0 = oS + (wm + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
-    const uint32_t fb0 = oS + 256 * 64 + (wn + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
-    i32x4g fA[2][4], fB[2][2];   // [k-block][tile]
+    const uint32_t fb0 = oS + BM * 64 + (wn + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
+    i32x4g fA[2][MT], fB[2][NT];   // [k-block][tile]
     auto frags = [&, &fA = fA, &fB = fB](auto kkc, int s) {   // (explicit captures: clang wants them for asm operands in generic lambdas)
         constexpr int kk = decltype(kkc)::value;
-        const uint32_t so = (uint32_t)(s % kG2NS) * kG2Stage;
+        const uint32_t so = (uint32_t)(s % kG2NS) * kStage;
         const uint32_t pa = (fa0 + so) ^ (kk * 32), pb = (fb0 + so) ^ (kk * 32);
-        G256_FRAG(fB[kk][0], pb, 0); G256_FRAG(fB[kk][1], pb, 2048);
-        G256_FRAG(fA[kk][0], pa, 0); G256_FRAG(fA[kk][1], pa, 2048); G256_FRAG(fA[kk][2], pa, 4096); G256_FRAG(fA[kk][3], pa, 6144);
+        static_for_g<0, NT>([&fB = fB, pb](auto tc) { G256_FRAG(fB[kk][decltype(tc)::value], pb, decltype(tc)::value * 2048); });
+        static_for_g<0, MT>([&fA = fA, pa](auto tc) { G256_FRAG(fA[kk][decltype(tc)::value], pa, decltype(tc)::value * 2048); });
+    };
+    auto landed = [&, &fA = fA, &fB = fB](auto kkc) {   // the fragments of a k-block have landed (the wait is in front): tie them to it
+        constexpr int kk = decltype(kkc)::value;
+        static_for_g<0, NT>([&fB = fB](auto tc) { asm volatile("" : "+v"(fB[kk][decltype(tc)::value])); });
+        static_for_g<0, MT>([&fA = fA](auto tc) { asm volatile("" : "+v"(fA[kk][decltype(tc)::value])); });
     };
     auto mfmas = [&, &fA = fA, &fB = fB](auto kkc) {
         constexpr int kk = decltype(kkc)::value;
+        if constexpr (std::is_same_v<E, float>) {
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, fA[kk][a]), __builtin_bit_cast(bf16x8g, fB[kk][b]), acc[a][b], 0, 0, 0);
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        // (element copies first: __builtin_bit_cast applied to the element expression itself compiled to element 0
+                        //  for every e with this hipcc -- found from the ISA, four identical MFMAs per tile)
+                        const int ai = fA[kk][a][e], bi = fB[kk][b][e];
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, ai), __builtin_bit_cast(float, bi), acc[a][b], 0, 0, 0);
+                    }
+        } else {
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8g, fA[kk][a]), __builtin_bit_cast(bf16x8g, fB[kk][b]), acc[a][b], 0, 0, 0);
+        }
     };
     using K0 = std::integral_constant<int, 0>;
     using K1 = std::integral_constant<int, 1>;
     // stage 0 for everyone, then the first k-block of step 0 into registers
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ND) : "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     frags(K0{}, 0);
     for (int s = 0; s < nsteps; ++s) {
         // this wave's share of stage s + 1 has landed (younger: stage s + 2); the fragments requested in the previous step too
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)"
-                     : "+v"(fA[0][0]), "+v"(fA[0][1]), "+v"(fA[0][2]), "+v"(fA[0][3]), "+v"(fB[0][0]), "+v"(fB[0][1])
-                     :
-                     : "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(ND) : "memory");
+        landed(K0{});
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         frags(K1{}, s);              // second k-block of this step: stage s is complete since the previous barrier
         dma_all(s + kG2PD);          // into the stage read in step s - 1: everyone is past it
         mfmas(K0{});
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(fA[1][0]), "+v"(fA[1][1]), "+v"(fA[1][2]), "+v"(fA[1][3]), "+v"(fB[1][0]), "+v"(fB[1][1])
-                     :
-                     : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        landed(K1{});
         frags(K0{}, s + 1);          // first k-block of the next step: stage s + 1 is complete since this step's barrier
         mfmas(K1{});
+        if constexpr (kFoldSums) {
+            if ((s & 7) == 7) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b) {
+                        sum[a][b] += acc[a][b];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                    }
+            }
+        }
     }
     // (what was requested past the last step is still on its way: hold the registers and the stages until it has landed)
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
-                 : "+v"(fA[0][0]), "+v"(fA[0][1]), "+v"(fA[0][2]), "+v"(fA[0][3]), "+v"(fB[0][0]), "+v"(fB[0][1])
-                 :
-                 : "memory");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    landed(K0{});
     // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); A is the row operand
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NT; ++b) {
             const int k = k0 + wn + b * 32 + li;
             const float bv = bias ? (float)bias[k] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int64_t j = j0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (j < n) {
-                    const float v = acc[a][b][r] + bv;
+                    float v = acc[a][b][r] + bv;
+                    if constexpr (kFoldSums) v = (sum[a][b][r] + acc[a][b][r]) + bv;
                     if constexpr (OUT_BF16) ((__bf16 *)C_)[j * ldc + k] = (__bf16)v;
                     else ((float *)C_)[j * ldc + k] = accumulate ? ((const float *)C_)[j * ldc + k] + v : v;
                 }
             }
         }
+}
+
+// fp32 operands: C[n][c] (+)= sum_r A[n][r] * B[c][r] (+ bias[c]) on the LDS-DMA kernel (256 x 128 blocks); false when the shape is
+// not its own (Nc % 128, R % 16, rows not 16-byte aligned, fewer than 512 rows) and the caller keeps its 128 x 128 kernel
+bool gemm_rows_f32_256_usable(const float *A_, int lda, int64_t n, const float *B_, int ldb, int R, int Nc) {
+    bool ok = (Nc % 128) == 0 && (R % 16) == 0 && n >= 512 && !(lda & 3) && !(ldb & 3) && !(((uintptr_t)A_ | (uintptr_t)B_) & 15) &&
+              (int64_t)256 * (lda > ldb ? lda : ldb) * 4 < 0x7fffffffLL;
+#ifdef MOT_DEV_ABLATION
+    if (getenv("MOT_GEMM32_OLD")) ok = false;
+#endif
+    return ok;
+}
+int launch_gemm_rows_f32_256(const float *A_, int lda, int64_t n, const float *B_, int ldb, int R, int Nc, float *C, int ldc, const float *bias,
+                             bool accumulate, hipStream_t stream) {
+    const int64_t gx2 = (n + 255) / 256, blocks2 = (gx2 + 7) / 8 * 8 * (Nc / 128);
+    if (blocks2 > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows: too many rows");
+    static std::atomic<uint64_t> ok{0};
+    if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_256_kernel<float, false, 2, 2, 2>, ok, "gemm_rows_256_kernel")) return rc;
+    hipLaunchKernelGGL((gemm_rows_256_kernel<float, false, 2, 2, 2>), dim3((unsigned)blocks2), dim3(kG2Threads), (size_t)kG2NS * (256 + 128) * 64, stream, A_, lda, n,
+                       B_, ldb, R, Nc, (void *)C, ldc, bias, accumulate ? 1 : 0);
+    return check_launch("gemm_rows_256_kernel");
 }
 
 int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
@@ -272,18 +346,18 @@ int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, in
     if (big) {   // 256 x 256 blocks by LDS-DMA
         const int64_t gx2 = (n + 255) / 256, blocks2 = (gx2 + 7) / 8 * 8 * (Nc / 256);
         if (blocks2 > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: too many rows");
-        const size_t lds = (size_t)kG2NS * kG2Stage;
+        const size_t lds = (size_t)kG2NS * (256 + 256) * 64;
         static std::atomic<uint64_t> ok0{0}, ok1{0};
         if (out_bf16) {
-            if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_bf16_256_kernel<true>, ok1, "gemm_rows_bf16_256_kernel")) return rc;
-            hipLaunchKernelGGL((gemm_rows_bf16_256_kernel<true>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
+            if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_256_kernel<__bf16, true, 4, 2, 4>, ok1, "gemm_rows_256_kernel")) return rc;
+            hipLaunchKernelGGL((gemm_rows_256_kernel<__bf16, true, 4, 2, 4>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
                                (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, 0);
         } else {
-            if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_bf16_256_kernel<false>, ok0, "gemm_rows_bf16_256_kernel")) return rc;
-            hipLaunchKernelGGL((gemm_rows_bf16_256_kernel<false>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
+            if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_256_kernel<__bf16, false, 4, 2, 4>, ok0, "gemm_rows_256_kernel")) return rc;
+            hipLaunchKernelGGL((gemm_rows_256_kernel<__bf16, false, 4, 2, 4>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
                                (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, accumulate ? 1 : 0);
         }
-        return check_launch("gemm_rows_bf16_256_kernel");
+        return check_launch("gemm_rows_256_kernel");
     }
     const int gy = (Nc + 127) / 128;
     // (WM = 4, 256-row blocks on 8 waves, halves the reads of W per output but measured 3-7 % slower at 65 536 x 768 x 768)

@@ -68,6 +68,10 @@ int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64
 int launch_wave_ids16(const MotEmbedMixDesc &d, uint16_t *ids16, hipStream_t stream);   // ids from the token->byte table, 16-bit, + parity outputs
 int launch_gemm_rows_bf16(const void *A, int lda, int64_t n, const void *B, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
                           const void *bias, hipStream_t stream, bool accumulate = false);
+// the 256 x 256 LDS-DMA kernel of mot_gemm_bf16.hip with fp32 operands (B transposed: B[c][r])
+bool gemm_rows_f32_256_usable(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc);
+int launch_gemm_rows_f32_256(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc, float *C, int ldc, const float *bias, bool accumulate,
+                             hipStream_t stream);
 // C[m][k] += sum_n A[n][m] * B[n][k]  (bf16 row-major operands, fp32 atomics into C; mot_backward.hip); lda / ldb / M / Kc multiples of 8
 int launch_gemm_tn_bf16(const __bf16 *A, int lda, int M, const __bf16 *B, int ldb, int Kc, int64_t rows, float *C, int ldc, hipStream_t stream);
 int launch_narrow(const float *src, int64_t n, void *dst_bf16, hipStream_t stream);                                  // dst[i] = bf16(src[i])
