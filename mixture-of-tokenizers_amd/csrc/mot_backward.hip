@@ -783,7 +783,8 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_full_kernel(const B
 // ------------------------------------------------------------------------------------------
 constexpr int kLcThreads = 768, kLcWaves = kLcThreads / 64;   // 12 waves, 3 per SIMD: ~170 registers per lane, room for the next position's gradient row
 
-template <int MODE, int NE, bool DUAL>
+// T: the element type of the tables and of grad_out (float, or __bf16: rows widened as they are loaded; every sum stays fp32)
+template <int MODE, int NE, bool DUAL, typename T>
 __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdArgs A) {
 #pragma clang fp contract(fast)   // fused multiply-adds here: the sums below are compared with float64 at 2e-5, not bit for bit
     constexpr int D = 64 * NE, NV = NE / 4;
@@ -805,15 +806,16 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
     const int lps = BYTES ? A.Db / NE : 64;                       // lanes per slot
     const int slot = BYTES ? lane / lps : 0;
     const int wi0 = BYTES ? (lane - slot * lps) * NE : 0;
-    const uint32_t lane_off = (uint32_t)lane * (NE * 4u);
-    auto load_row = [&](const char *rbase, float (&dst)[NE]) {   // NE consecutive floats at rbase + lane_off
+    const uint32_t lane_off = (uint32_t)lane * (NE * (uint32_t)sizeof(T));
+    const T *grad_out = (const T *)A.grad_out, *tok_table = (const T *)A.tok_table, *byte_table = (const T *)A.byte_table;
+    auto load_row = [&](const char *rbase, float (&dst)[NE]) {   // NE consecutive elements at rbase + lane_off
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            const float4v w = *(const float4v *)(rbase + (lane_off + 16u * v));
+            const float4v w = Elem<T>::load4((const T *)(rbase + (lane_off + 4u * (uint32_t)sizeof(T) * v)));
             dst[4 * v] = w.x; dst[4 * v + 1] = w.y; dst[4 * v + 2] = w.z; dst[4 * v + 3] = w.w;
         }
     };
-    auto load_byte_row = [&](int id, float (&dst)[NE]) { load_row((const char *)(A.byte_table + (int64_t)id * A.Db + wi0) - lane_off, dst); };
+    auto load_byte_row = [&](int id, float (&dst)[NE]) { load_row((const char *)(byte_table + (int64_t)id * A.Db + wi0) - lane_off, dst); };
     auto slot_sum = [&](float v) {                                // sum over the lanes of this lane's slot (lps a power of two)
         for (int o = 1; o < lps; o <<= 1) v += __shfl_xor(v, o, 64);
         return v;
@@ -845,7 +847,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
         float gmax = 0.f;
         if (s_begin < s_end) {
             float gs[NE];
-            load_row((const char *)(A.grad_out + (int64_t)A.pos_sorted[s_begin] * D), gs);
+            load_row((const char *)(grad_out + (int64_t)A.pos_sorted[s_begin] * D), gs);
 #pragma unroll
             for (int j = 0; j < NE; ++j) gmax = fmaxf(gmax, fabsf(gs[j]));
             gmax = wave_max(gmax) * fabsf(s_byte);
@@ -874,7 +876,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
         float g_nx[NE], b_nx[NE], rn_nx = 1.f;
         int ida_nx = 0, idb_nx = 0;
         int64_t ida_n2 = 0, idb_n1 = 0;                           // raw: the first id tensor's entry two positions ahead, the second's one ahead
-        load_row((const char *)(A.grad_out + (int64_t)n0 * D), g_nx);
+        load_row((const char *)(grad_out + (int64_t)n0 * D), g_nx);
         if (BYTES) {
             ida_nx = clamp_id(load_id(A.ids_a, n0));
             if (DUAL) idb_nx = clamp_id(load_id(A.ids_b, n0));
@@ -898,11 +900,11 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
             if (newrun) {   // the previous token's gradient row leaves, this token's row comes in
                 flush();
                 cur = tok;
-                load_row((const char *)(A.tok_table + (int64_t)tok * D), an);
+                load_row((const char *)(tok_table + (int64_t)tok * D), an);
             }
             if (more) {   // the next position's rows, the byte ids of the one after
                 const int nn = __builtin_amdgcn_readlane(vpos, k + 1);
-                load_row((const char *)(A.grad_out + (int64_t)nn * D), g_nx);
+                load_row((const char *)(grad_out + (int64_t)nn * D), g_nx);
                 if (BYTES) {
                     ida_nx = clamp_id(ida_n2);
                     if (DUAL) idb_nx = clamp_id(idb_n1);
@@ -1030,7 +1032,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
 
 template <int MODE>
 static bool lc_layout(const BwdArgs &A) {
-    if (A.in_bf16 || (A.D & 255) || A.Dt != A.D || A.tok_lo != 0 || A.D > 1024) return false;
+    if ((A.D & 255) || A.Dt != A.D || A.tok_lo != 0 || A.D > 1024) return false;
     const int ne = A.D / 64;
     if (MODE == MOT_MIX_SUM) {
         if (A.byte_lo != 0 || A.nbk != A.D || A.Db % ne) return false;
@@ -1041,13 +1043,19 @@ static bool lc_layout(const BwdArgs &A) {
     return ne == 4 || ne == 8 || ne == 12 || ne == 16;   // 1024-thread workgroups cap a lane at 128 registers: NE 24 / 32 would spill
 }
 
+template <int MODE, int NE, bool DUAL, typename T>
+static int launch_bwd_lc_tt(const BwdArgs &A, size_t lds, hipStream_t stream);
 template <int MODE, int NE, bool DUAL>
 static int launch_bwd_lc_t(const BwdArgs &A, size_t lds, hipStream_t stream) {
+    return A.in_bf16 ? launch_bwd_lc_tt<MODE, NE, DUAL, __bf16>(A, lds, stream) : launch_bwd_lc_tt<MODE, NE, DUAL, float>(A, lds, stream);
+}
+template <int MODE, int NE, bool DUAL, typename T>
+static int launch_bwd_lc_tt(const BwdArgs &A, size_t lds, hipStream_t stream) {
     static std::atomic<uint64_t> lds_ok{0};   // per-device bits
-    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_lc_kernel<MODE, NE, DUAL>, lds_ok, "embed_mix_bwd_lc_kernel")) return rc_lds;
+    if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mix_bwd_lc_kernel<MODE, NE, DUAL, T>, lds_ok, "embed_mix_bwd_lc_kernel")) return rc_lds;
     int64_t blocks = (A.n_tokens + 16 * kLcWaves - 1) / (16 * kLcWaves);   // >= 16 sorted positions per wave
     if (blocks > 256) blocks = 256;   // one workgroup per CU
-    hipLaunchKernelGGL((embed_mix_bwd_lc_kernel<MODE, NE, DUAL>), dim3((unsigned)blocks), dim3(kLcThreads), lds, stream, A);
+    hipLaunchKernelGGL((embed_mix_bwd_lc_kernel<MODE, NE, DUAL, T>), dim3((unsigned)blocks), dim3(kLcThreads), lds, stream, A);
     return check_launch("embed_mix_bwd_lc_kernel");
 }
 template <int MODE, int NE>
