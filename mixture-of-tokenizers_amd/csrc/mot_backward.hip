@@ -75,6 +75,9 @@ struct BwdArgs {
     const int32_t *pos_sorted;  // token positions ordered by token id
     const int32_t *tok_sorted;  // their (clamped) token ids
     int in_bf16;  // tables and grad_out are bf16 (gradients are accumulated and returned in fp32 either way)
+    // lane-contiguous kernel only (the two halves of the CONCAT_LINEAR scatter): elements between gradient rows when they are columns of
+    // a wider matrix (0: D), and "no token table" (SUM over byte slots only: nothing is read from or added to a token table)
+    int g_ld, no_tok;
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
 };
 
@@ -808,6 +811,8 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
     const int wi0 = BYTES ? (lane - slot * lps) * NE : 0;
     const uint32_t lane_off = (uint32_t)lane * (NE * (uint32_t)sizeof(T));
     const T *grad_out = (const T *)A.grad_out, *tok_table = (const T *)A.tok_table, *byte_table = (const T *)A.byte_table;
+    const int64_t gld = A.g_ld ? A.g_ld : D;                      // elements between gradient rows
+    const bool no_tok = A.no_tok != 0;                            // byte slots only: no token row is read, none is written
     auto load_row = [&](const char *rbase, float (&dst)[NE]) {   // NE consecutive elements at rbase + lane_off
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -829,7 +834,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
     float ra = 1.f, ds_t = 0.f, ds_b = 0.f;
     int cur = -1;
     auto flush = [&]() {
-        if (cur < 0) return;
+        if (cur < 0 || no_tok) return;
 #pragma unroll
         for (int v = 0; v < NV; ++v) *(float4v *)(xp + lane * NE + 4 * v) = float4v{acc[4 * v], acc[4 * v + 1], acc[4 * v + 2], acc[4 * v + 3]};
         seg_sync();
@@ -847,7 +852,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
         float gmax = 0.f;
         if (s_begin < s_end) {
             float gs[NE];
-            load_row((const char *)(grad_out + (int64_t)A.pos_sorted[s_begin] * D), gs);
+            load_row((const char *)(grad_out + (int64_t)A.pos_sorted[s_begin] * gld), gs);
 #pragma unroll
             for (int j = 0; j < NE; ++j) gmax = fmaxf(gmax, fabsf(gs[j]));
             gmax = wave_max(gmax) * fabsf(s_byte);
@@ -876,7 +881,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
         float g_nx[NE], b_nx[NE], rn_nx = 1.f;
         int ida_nx = 0, idb_nx = 0;
         int64_t ida_n2 = 0, idb_n1 = 0;                           // raw: the first id tensor's entry two positions ahead, the second's one ahead
-        load_row((const char *)(grad_out + (int64_t)n0 * D), g_nx);
+        load_row((const char *)(grad_out + (int64_t)n0 * gld), g_nx);
         if (BYTES) {
             ida_nx = clamp_id(load_id(A.ids_a, n0));
             if (DUAL) idb_nx = clamp_id(load_id(A.ids_b, n0));
@@ -900,11 +905,14 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
             if (newrun) {   // the previous token's gradient row leaves, this token's row comes in
                 flush();
                 cur = tok;
-                load_row((const char *)(tok_table + (int64_t)tok * D), an);
+                if (no_tok) {
+#pragma unroll
+                    for (int j = 0; j < NE; ++j) an[j] = 0.f;
+                } else load_row((const char *)(tok_table + (int64_t)tok * D), an);
             }
             if (more) {   // the next position's rows, the byte ids of the one after
                 const int nn = __builtin_amdgcn_readlane(vpos, k + 1);
-                load_row((const char *)(grad_out + (int64_t)nn * D), g_nx);
+                load_row((const char *)(grad_out + (int64_t)nn * gld), g_nx);
                 if (BYTES) {
                     ida_nx = clamp_id(ida_n2);
                     if (DUAL) idb_nx = clamp_id(idb_n1);
@@ -1367,7 +1375,7 @@ template <int MODE>
 static bool plain_layout(const BwdArgs &A) {
     if ((A.D & 255) || A.D > 768 || A.Dt != A.D || A.tok_lo != 0) return false;
     if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D)) return false;
-    if (A.norm_tok || A.norm_byte || A.scale_tok || A.scale_byte || A.d_scale_tok || A.d_scale_byte || A.ids_b) return false;
+    if (A.norm_tok || A.norm_byte || A.scale_tok || A.scale_byte || A.d_scale_tok || A.d_scale_byte || A.ids_b || A.g_ld || A.no_tok) return false;
     if (MODE == MOT_MIX_SUM && ((A.Db & 3) || A.Db > 128)) return false;   // a chunk of a row lies inside one byte slot; wide byte rows
                                                                             // (the D-wide "slot" of the cross-attention mixin's two-id backward) do
                                                                             // not fit LDS, and this kernel's path for rows without an LDS slot is slow
@@ -1686,6 +1694,7 @@ static void fill_bwd_args(BwdArgs &A, const MotEmbedMixDesc &d, const MotEmbedMi
     A.d_scale_tok = gr.d_scale_tok; A.d_scale_byte = gr.d_scale_byte;
     A.status = d.status;
     A.pos_sorted = A.tok_sorted = nullptr;
+    A.g_ld = 0; A.no_tok = 0;
     if (gr.token_order) {   // [counts: rows][starts: rows][rank: n][pos_sorted: n][tok_sorted: n], as launch_group_positions lays it out
         const int64_t n = d.n_rows * d.tokens_per_row;
         A.pos_sorted = gr.token_order + 2 * d.tok_rows + n;
@@ -2460,6 +2469,25 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     fill_bwd_args(A, d, gr);
     A.grad_out = du; A.D = K; A.norm_out = 0;
     A.Dt = Dt; A.tok_lo = tok_lo; A.byte_lo = byte_lo; A.nbk = nbk;
+    // The two halves of a du row are two embedding backwards: the token part a plain one (NOOP) over Dt columns, the byte part a SUM
+    // over byte slots with no token table -- both on the lane-contiguous kernel, reading their columns of du in place (row stride K),
+    // sharing one grouping of the positions.  (The strided kernel of round 1 took 242 us of the 870 us the bf16 concat forward +
+    // backward takes at 65 536 tokens.)  One id tensor only: norm_byte over two id tensors normalises the SUM of two rows.
+    if (!d.ids_b) {
+        BwdArgs At = A, Ab = A;
+        At.D = At.Dt = Dt; At.tok_lo = At.byte_lo = 0; At.nbk = 0; At.grad_out = du + tok_lo; At.g_ld = K; At.d_byte = nullptr;
+        Ab.D = Ab.Dt = nbk; Ab.tok_lo = Ab.byte_lo = 0; Ab.nbk = nbk; Ab.grad_out = du + byte_lo; Ab.g_ld = K; Ab.no_tok = 1; Ab.d_tok = nullptr;
+        Ab.norm_tok = 0; Ab.tok_table = nullptr;
+        bool split = lc_layout<MOT_MIX_NOOP>(At) && lc_layout<MOT_MIX_SUM>(Ab);
+#ifdef MOT_DEV_ABLATION
+        if (getenv("MOT_CONCAT_SCATTER_OLD")) split = false;
+#endif
+        if (split) {
+            if ((rc = run_scatter<MOT_MIX_NOOP>(At, d, sort_ints, rn, stream))) return rc;
+            Ab.pos_sorted = At.pos_sorted; Ab.tok_sorted = At.tok_sorted;
+            return run_scatter<MOT_MIX_SUM>(Ab, d, sort_ints, rn, stream);
+        }
+    }
     return run_scatter<MOT_MIX_CONCAT_LINEAR>(A, d, sort_ints, rn, stream);
 }
 
