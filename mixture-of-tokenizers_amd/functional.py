@@ -578,8 +578,10 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
 
 
 def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                     bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul=None):
-    """Validated MotCrossAttnDesc for both directions; returns (desc, keepalive list, device, T, D)."""
+                     bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul=None, widened=None):
+    """Validated MotCrossAttnDesc for both directions; returns (desc, keepalive list, device, T, D).  `widened`: the fp32 copies
+    (tables, weights, lambda) an earlier call of the same autograd node made of the same bf16 operands -- keep[1:7] -- reused
+    instead of made again."""
     dev = capi.require_device(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k)
     T = tokens.shape[1]
     tok = tokens.to(torch.int32) if tokens.dtype != torch.int32 else tokens
@@ -598,15 +600,22 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
         raise TypeError(f"cross_attn: byte table is {byte_table.dtype} but the token table is {tok_table.dtype}")
     wide = (lambda t: t.detach().float()) if bf else (lambda t: t.detach())
     as_used = (lambda w: w.detach().to(torch.bfloat16).float()) if bf else (lambda w: w.detach())
-    tt, bt = _contig(wide(tok_table), f32, "tok_table"), _contig(wide(byte_table), f32, "byte_table")
+    if widened is not None:   # (the backward of a bf16 step: the forward's copies; autograd has checked that the originals are unchanged)
+        wide = as_used = None
+        tt, bt = widened[0], widened[1]
+    else:
+        tt, bt = _contig(wide(tok_table), f32, "tok_table"), _contig(wide(byte_table), f32, "byte_table")
     D = tt.shape[1]
     if bt.shape[1] != D:
         raise AssertionError("cross_attn: byte_dim == token_dim == model_dim (train_gpt.py:449)")
     HD = n_heads * 128
-    qw, kvw, pw = _contig(as_used(q_w), f32, "q_w"), _contig(as_used(kv_w), f32, "kv_w"), _contig(as_used(proj_w), f32, "proj_w")
+    if widened is not None:
+        qw, kvw, pw = widened[2], widened[3], widened[4]
+    else:
+        qw, kvw, pw = _contig(as_used(q_w), f32, "q_w"), _contig(as_used(kv_w), f32, "kv_w"), _contig(as_used(proj_w), f32, "proj_w")
     if qw.shape != (HD, D) or kvw.shape != (2, HD, D) or pw.shape != (D, HD):
         raise AssertionError(f"cross_attn: weights {tuple(qw.shape)}, {tuple(kvw.shape)}, {tuple(pw.shape)} do not fit heads={n_heads}, dim={D}")
-    lam = _contig(as_used(lambda_factor).reshape(1), f32, "lambda_factor")
+    lam = widened[5] if widened is not None else _contig(as_used(lambda_factor).reshape(1), f32, "lambda_factor")
     ia = _contig(ids_a.reshape(-1), torch.int64, "ids_a")
     ib = None if ids_b is None else _contig(ids_b.reshape(-1), torch.int64, "ids_b")
     if ia.numel() != T * bpt or (ib is not None and ib.numel() != T * bpt):
@@ -641,14 +650,16 @@ class _CrossAttnFn(torch.autograd.Function):
         ctx.save_for_backward(tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, saved, *rot)
         ctx.ids_b = ids_b          # (an integer tensor or None: nothing autograd tracks)
         ctx.kw = kw
-        x = _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, *rot, saved_qy=saved, **kw)
+        # bf16 tables: the fp32 copies of the operands this call makes serve the backward too (six conversions less per step)
+        ctx.widened = [] if tok_table.dtype == torch.bfloat16 else None
+        x = _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, *rot, saved_qy=saved, _keep_widened=ctx.widened, **kw)
         return x.to(tok_table.dtype)
 
     @staticmethod
     def backward(ctx, gx):
         tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, tokens, ids_a, saved, cq, sq, ck, sk = ctx.saved_tensors
         g = cross_attn_backward(gx, tokens, ids_a, tok_table, byte_table, q_w=q_w, kv_w=kv_w, proj_w=proj_w, lambda_factor=lambda_factor,
-                                cos_q=cq, sin_q=sq, cos_k=ck, sin_k=sk, saved_qy=saved, ids_b=ctx.ids_b, **ctx.kw)
+                                cos_q=cq, sin_q=sq, cos_k=ck, sin_k=sk, saved_qy=saved, ids_b=ctx.ids_b, widened=ctx.widened or None, **ctx.kw)
         # fp32 sums; the tables' gradients are rounded once to the tables' dtype (bf16 in production), the weights stay fp32 masters
         return (g["tok_table"].to(tok_table.dtype), g["byte_table"].to(byte_table.dtype), g["q_w"], g["kv_w"], g["proj_w"],
                 g["lambda_factor"].reshape(lambda_factor.shape).to(lambda_factor.dtype), None, None, None, None, None)
@@ -657,14 +668,14 @@ class _CrossAttnFn(torch.autograd.Function):
 @torch.compiler.disable
 def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
                         bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, saved_qy=None, ids_b=None,
-                        matmul=None) -> dict:
+                        matmul=None, widened=None) -> dict:
     """One call of mot_cross_attn_bwd: dense fp32 gradients {tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor}.
     `saved_qy`: the buffer the forward filled (projected queries + attention output); without it they are recomputed.
     `ids_b`: the second id tensor of the add_padded_and_pulled embedding (train_gpt.py:364-372)."""
     if tokens.ndim == 1:
         tokens = tokens[None]
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul)
+                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul, widened)
     g = _contig(grad_out.reshape(T, D).float(), torch.float32, "grad_out")
     out = {"tok_table": torch.zeros_like(keep[1]), "byte_table": torch.zeros_like(keep[2]), "q_w": torch.zeros_like(keep[3]),
            "kv_w": torch.zeros_like(keep[4]), "proj_w": torch.zeros_like(keep[5]), "lambda_factor": torch.zeros(1, dtype=torch.float32, device=dev)}
@@ -684,9 +695,12 @@ def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, 
 
 
 def _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k, *,
-                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None, saved_qy=None, matmul=None):
+                    bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None, saved_qy=None, matmul=None,
+                    _keep_widened=None):
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
                                           bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul)
+    if _keep_widened is not None:
+        _keep_widened.extend(keep[1:7])   # tt, bt, qw, kvw, pw, lam
     out = torch.empty((1, T, D), dtype=torch.float32, device=dev)
     d.out = capi.ptr(out)
     if saved_qy is not None:
