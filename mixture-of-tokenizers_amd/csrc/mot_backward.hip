@@ -2314,6 +2314,17 @@ int launch_narrow(const float *src, int64_t n, void *dst, hipStream_t stream) {
     return check_launch("narrow_kernel");
 }
 
+// out[n] = ids[n * bpt + k] as int32 (out-of-range ids flagged and clamped to 0, as the forward does): one byte slot's ids as the
+// "tokens" of a plain embedding backward (the slot-wise scatter of wide concat rows, below)
+__global__ __launch_bounds__(kThreads) void ids_column_i32_kernel(const int64_t *__restrict__ ids, int64_t n, int bpt, int k, int64_t rows, int32_t *__restrict__ out,
+                                                                  uint32_t *status) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        int64_t v = ids[i * bpt + k];
+        if ((uint64_t)v >= (uint64_t)rows) { if (status) atomicOr(status, kStatusByteOor); v = 0; }
+        out[i] = (int32_t)v;
+    }
+}
+
 static size_t bwd_rnorm_floats(const MotEmbedMixDesc &d) { return d.mode == MOT_MIX_SUM ? ((size_t)d.byte_rows + 3) & ~(size_t)3 : 0; }
 size_t embed_mix_bwd_mean_workspace_bytes(const MotEmbedMixDesc &d);
 size_t embed_mix_bwd_workspace_bytes(const MotEmbedMixDesc &d) {
@@ -2335,7 +2346,11 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     if (d.norm_out && (!d.out || !d.out_row_rnorm)) return set_error(MOT_EINVAL, "embed_mix_bwd concat_linear: needs the forward's out and out_row_rnorm");
     const int64_t N = d.n_rows * d.tokens_per_row;
     const int Dm = d.model_dim, Dt = d.tok_dim, nbk = d.bpt * d.byte_dim, K = Dt + nbk;
-    if (K > 1024 || Dm > 2048) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 or model_dim %d > 2048", K, Dm);
+    // rows wider than 1024 (mathblations' defaults: 768 + 3 x 768, model.py:21-24, 256-268) only where the table gradients can be
+    // scattered part by part on the lane-contiguous kernel: token part and every byte slot a multiple of 256 columns, <= 1024 each
+    const bool wide_ok = !d.ids_b && !d.scale_tok && !d.scale_byte && (Dt & 255) == 0 && Dt <= 1024 && (d.byte_dim & 255) == 0 && d.byte_dim <= 1024;
+    if ((K > 1024 && !wide_ok) || Dm > 2048)
+        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 (with parts that are not multiples of 256 columns <= 1024) or model_dim %d > 2048", K, Dm);
     const LinBwdLayout L = lin_bwd_layout(d);
     if (d.dtype == MOT_BF16) {
         const UpLayout U = up_layout(d);
@@ -2487,7 +2502,26 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
             Ab.pos_sorted = At.pos_sorted; Ab.tok_sorted = At.tok_sorted;
             return run_scatter<MOT_MIX_SUM>(Ab, d, sort_ints, rn, stream);
         }
+        // Wide byte slots (a slot is a whole embedding row: the digit mixin): every slot is a plain embedding backward of its own, the
+        // slot's ids as the "tokens", the byte table as the table, its columns of du as the gradient rows
+        if (lc_layout<MOT_MIX_NOOP>(At) && (d.byte_dim & 255) == 0 && d.byte_dim <= 1024 && !d.scale_tok && !d.scale_byte) {
+            if ((rc = run_scatter<MOT_MIX_NOOP>(At, d, sort_ints, rn, stream))) return rc;
+            for (int k = 0; k < d.bpt; ++k) {
+                hipLaunchKernelGGL(ids_column_i32_kernel, dim3(256), dim3(kThreads), 0, stream, d.ids_a, N, d.bpt, k, d.byte_rows, iota, d.status);
+                if ((rc = check_launch("ids_column_i32_kernel"))) return rc;
+                BwdArgs As = A;
+                As.tokens = iota; As.tok_table = A.byte_table; As.tok_rows = d.byte_rows; As.norm_tok = d.norm_byte;
+                As.D = As.Dt = d.byte_dim; As.tok_lo = As.byte_lo = 0; As.nbk = 0; As.grad_out = du + byte_lo + k * d.byte_dim; As.g_ld = K;
+                As.d_tok = A.d_byte; As.d_byte = nullptr; As.pos_sorted = As.tok_sorted = nullptr;
+                if (!lc_layout<MOT_MIX_NOOP>(As)) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: byte slots of %d columns", d.byte_dim);
+                MotEmbedMixDesc ds = d;   // (run_scatter reads the table height from the descriptor)
+                ds.tok_rows = d.byte_rows;
+                if ((rc = run_scatter<MOT_MIX_NOOP>(As, ds, sort_ints, rn, stream))) return rc;
+            }
+            return MOT_OK;
+        }
     }
+    if (K > 1024) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 needs the part-wise scatter (one id tensor, no learned scalars)", K);
     return run_scatter<MOT_MIX_CONCAT_LINEAR>(A, d, sort_ints, rn, stream);
 }
 

@@ -131,6 +131,8 @@ def test_mathblations_backward_vs_reference_autograd(mot):
     (256, 48, 16, 1024, 2048, 2, 160, dict(norm_tok=True, norm_byte=True, norm_out=True, dual=True), 9206),  # norm(emb(padded)+emb(pulled))
     (64, 24, 7, 96, 300, 3, 50, dict(norm_byte=True, dual=True, scaled=True, bias=True), 9207),               # ragged slots across lanes
     (128, 32, 8, 256, 512, 2, 90, dict(norm_tok=True, dual=True), 9208),                                    # two id tensors, no byte norm
+    (768, 768, 3, 768, 1003, 4, 96, dict(bias=True, bytes_first=True), 9209),       # mathblations DEFAULT dims (model.py:21-24): K = 3072, slot-wise scatter
+    (256, 256, 5, 512, 600, 2, 70, dict(norm_tok=True, norm_byte=True, norm_out=True), 9210),   # wide rows with every norm (K = 1536)
 ])
 def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     kw = dict(kw)
