@@ -219,6 +219,9 @@ def _mix_concat(h_or_tok, byte_embs, *, bpt: int, weight: Tensor, bias: Tensor |
     _check_forward_only(weight, bias)
     if tok_embs.requires_grad or byte_embs.requires_grad:
         _check_forward_only(tok_embs, byte_embs)
+    if tok_embs.dtype != weight.dtype:       # CastedLinear.forward: self.weight.type_as(x)  (train_gpt.py:185-186), as on the fused path
+        weight = weight.to(tok_embs.dtype)
+        bias = None if bias is None else bias.to(tok_embs.dtype)
     B, T, Dt = tok_embs.shape
     Db = byte_embs.shape[-1]
     dev = tok_embs.device

@@ -328,6 +328,17 @@ def test_bf16_modules_cast_the_weight_like_casted_linear(mot):
     with torch.no_grad():
         x = mixin(*embed(toks, ids, ids))
     assert x.dtype == torch.bfloat16 and x.shape == (B, T, Dm) and bool(torch.isfinite(x.float()).all())
+    # the materialised seam (fused=False: dense bf16 embeddings into the mixin) casts the weight the same way and gives the same rows
+    embed2 = M.FlexibleEmbedding(dims, Vt, bp, fused=False).to(DEV)
+    embed2.load_state_dict(embed.state_dict())
+    for m in embed2.modules():
+        if isinstance(m, torch.nn.Embedding):
+            m.bfloat16()
+    with torch.no_grad():
+        te, be = embed2(toks, ids, ids)
+        x2 = mixin(te, be)
+    assert te.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+    assert (x2.float() - x.float()).abs().max() <= 2.0 ** -6 * x.float().abs().max()   # (the dense path rounds the normalised rows once more)
 
 
 # ------------------------------------------------------------------------------------------------
