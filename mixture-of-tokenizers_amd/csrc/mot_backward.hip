@@ -78,6 +78,7 @@ struct BwdArgs {
     // lane-contiguous kernel only (the two halves of the CONCAT_LINEAR scatter): elements between gradient rows when they are columns of
     // a wider matrix (0: D), and "no token table" (SUM over byte slots only: nothing is read from or added to a token table)
     int g_ld, no_tok;
+    int slot0;    // first byte slot of this pass (its ids are ids[n * bpt + slot0 + ...]): the byte part taken in column blocks
     int abl;  // dev-only timing ablations (MOT_DEV_ABLATION builds): 1 no LDS byte adds, 2 no token-row flush, 4 no wave sums
 };
 
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(kLcThreads) void embed_mix_bwd_lc_kernel(const BwdA
     }
     // the id of this lane's slot: requested raw, range-checked where it is first used (a check right behind the load would make
     // the wave wait for everything it has in flight)
-    auto load_id = [&](const int64_t *ids, int64_t n) { return *(const int64_t *)((const char *)(ids + n * A.bpt) + (uint32_t)slot * 8u); };
+    auto load_id = [&](const int64_t *ids, int64_t n) { return *(const int64_t *)((const char *)(ids + n * A.bpt + A.slot0) + (uint32_t)slot * 8u); };
     auto clamp_id = [&](int64_t v) {
         if ((uint64_t)v >= (uint64_t)A.byte_rows) { if (A.status) atomicOr(A.status, kStatusByteOor); v = 0; }
         return (int)v;
@@ -1375,7 +1376,7 @@ template <int MODE>
 static bool plain_layout(const BwdArgs &A) {
     if ((A.D & 255) || A.D > 768 || A.Dt != A.D || A.tok_lo != 0) return false;
     if (MODE == MOT_MIX_SUM && (A.byte_lo != 0 || A.nbk != A.D)) return false;
-    if (A.norm_tok || A.norm_byte || A.scale_tok || A.scale_byte || A.d_scale_tok || A.d_scale_byte || A.ids_b || A.g_ld || A.no_tok) return false;
+    if (A.norm_tok || A.norm_byte || A.scale_tok || A.scale_byte || A.d_scale_tok || A.d_scale_byte || A.ids_b || A.g_ld || A.no_tok || A.slot0) return false;
     if (MODE == MOT_MIX_SUM && ((A.Db & 3) || A.Db > 128)) return false;   // a chunk of a row lies inside one byte slot; wide byte rows
                                                                             // (the D-wide "slot" of the cross-attention mixin's two-id backward) do
                                                                             // not fit LDS, and this kernel's path for rows without an LDS slot is slow
@@ -1694,7 +1695,7 @@ static void fill_bwd_args(BwdArgs &A, const MotEmbedMixDesc &d, const MotEmbedMi
     A.d_scale_tok = gr.d_scale_tok; A.d_scale_byte = gr.d_scale_byte;
     A.status = d.status;
     A.pos_sorted = A.tok_sorted = nullptr;
-    A.g_ld = 0; A.no_tok = 0;
+    A.g_ld = 0; A.no_tok = 0; A.slot0 = 0;
     if (gr.token_order) {   // [counts: rows][starts: rows][rank: n][pos_sorted: n][tok_sorted: n], as launch_group_positions lays it out
         const int64_t n = d.n_rows * d.tokens_per_row;
         A.pos_sorted = gr.token_order + 2 * d.tok_rows + n;
@@ -2115,7 +2116,7 @@ static Du16Layout du16_layout(const MotEmbedMixDesc &d) {
 }
 static bool du16_usable(const MotEmbedMixDesc &d) {
     const int K = d.tok_dim + d.bpt * d.byte_dim;
-    return d.dtype == MOT_BF16 && (d.model_dim & 7) == 0 && (K & 7) == 0 && K <= 1024 && ((d.n_rows * d.tokens_per_row) & 7) == 0 &&
+    return d.dtype == MOT_BF16 && (d.model_dim & 7) == 0 && (K & 7) == 0 && K <= 4096 && ((d.n_rows * d.tokens_per_row) & 7) == 0 &&
            !(d.flags & MOT_FLAG_BWD_DU_FP32);
 }
 
@@ -2348,9 +2349,9 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
     const int Dm = d.model_dim, Dt = d.tok_dim, nbk = d.bpt * d.byte_dim, K = Dt + nbk;
     // rows wider than 1024 (mathblations' defaults: 768 + 3 x 768, model.py:21-24, 256-268) only where the table gradients can be
     // scattered part by part on the lane-contiguous kernel: token part and every byte slot a multiple of 256 columns, <= 1024 each
-    const bool wide_ok = !d.ids_b && !d.scale_tok && !d.scale_byte && (Dt & 255) == 0 && Dt <= 1024 && (d.byte_dim & 255) == 0 && d.byte_dim <= 1024;
-    if ((K > 1024 && !wide_ok) || Dm > 2048)
-        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 (with parts that are not multiples of 256 columns <= 1024) or model_dim %d > 2048", K, Dm);
+    // (rows up to 2048 columns: the strided kernels take them whole; wider ones -- the reference's dimension sweeps reach 1024 + 16 x
+    //  128 = 3072, experiments100_000steps.sh, mathblations' defaults 768 + 3 x 768 -- only where the part-wise scatter below applies)
+    if (Dm > 2048) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: model_dim %d > 2048", Dm);
     const LinBwdLayout L = lin_bwd_layout(d);
     if (d.dtype == MOT_BF16) {
         const UpLayout U = up_layout(d);
@@ -2493,14 +2494,23 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         At.D = At.Dt = Dt; At.tok_lo = At.byte_lo = 0; At.nbk = 0; At.grad_out = du + tok_lo; At.g_ld = K; At.d_byte = nullptr;
         Ab.D = Ab.Dt = nbk; Ab.tok_lo = Ab.byte_lo = 0; Ab.nbk = nbk; Ab.grad_out = du + byte_lo; Ab.g_ld = K; Ab.no_tok = 1; Ab.d_tok = nullptr;
         Ab.norm_tok = 0; Ab.tok_table = nullptr;
-        bool split = lc_layout<MOT_MIX_NOOP>(At) && lc_layout<MOT_MIX_SUM>(Ab);
+        // the byte part in blocks of whole slots, <= 1024 columns each (16 x 128-wide slots are two blocks of 8)
+        int per = d.bpt;
+        while (per > 1 && per * d.byte_dim > 1024) per = (per + 1) / 2;
+        Ab.D = Ab.Dt = Ab.nbk = per * d.byte_dim;
+        bool split = lc_layout<MOT_MIX_NOOP>(At) && d.bpt % per == 0 && lc_layout<MOT_MIX_SUM>(Ab);
 #ifdef MOT_DEV_ABLATION
         if (getenv("MOT_CONCAT_SCATTER_OLD")) split = false;
 #endif
         if (split) {
             if ((rc = run_scatter<MOT_MIX_NOOP>(At, d, sort_ints, rn, stream))) return rc;
-            Ab.pos_sorted = At.pos_sorted; Ab.tok_sorted = At.tok_sorted;
-            return run_scatter<MOT_MIX_SUM>(Ab, d, sort_ints, rn, stream);
+            for (int s0 = 0; s0 < d.bpt; s0 += per) {
+                BwdArgs Ac = Ab;
+                Ac.pos_sorted = At.pos_sorted; Ac.tok_sorted = At.tok_sorted;
+                Ac.slot0 = s0; Ac.grad_out = du + byte_lo + s0 * d.byte_dim;
+                if ((rc = run_scatter<MOT_MIX_SUM>(Ac, d, sort_ints, rn, stream))) return rc;
+            }
+            return MOT_OK;
         }
         // Wide byte slots (a slot is a whole embedding row: the digit mixin): every slot is a plain embedding backward of its own, the
         // slot's ids as the "tokens", the byte table as the table, its columns of du as the gradient rows
@@ -2521,7 +2531,9 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
             return MOT_OK;
         }
     }
-    if (K > 1024) return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 1024 needs the part-wise scatter (one id tensor, no learned scalars)", K);
+    if (K > 2048)
+        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 2048 needs the part-wise scatter (one id tensor, no learned scalars, token part a "
+                         "multiple of 256 columns <= 1024, byte slots that tile blocks of <= 1024 columns)", K);
     return run_scatter<MOT_MIX_CONCAT_LINEAR>(A, d, sort_ints, rn, stream);
 }
 

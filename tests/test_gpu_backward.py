@@ -133,6 +133,10 @@ def test_mathblations_backward_vs_reference_autograd(mot):
     (128, 32, 8, 256, 512, 2, 90, dict(norm_tok=True, dual=True), 9208),                                    # two id tensors, no byte norm
     (768, 768, 3, 768, 1003, 4, 96, dict(bias=True, bytes_first=True), 9209),       # mathblations DEFAULT dims (model.py:21-24): K = 3072, slot-wise scatter
     (256, 256, 5, 512, 600, 2, 70, dict(norm_tok=True, norm_byte=True, norm_out=True), 9210),   # wide rows with every norm (K = 1536)
+    # the reference's dimension sweeps (experiments100_000steps.sh: model 1024, bpt 16, token 768 / 896 / 1024 x byte 64 / 128)
+    (768, 64, 16, 1024, 900, 2, 48, dict(norm_tok=True, norm_byte=True, norm_out=True), 9211),    # K = 1792: token part + one block of 16 slots
+    (1024, 128, 16, 1024, 900, 2, 40, dict(norm_tok=True, norm_byte=True, norm_out=True), 9212),  # K = 3072: two blocks of 8 slots
+    (896, 64, 16, 1024, 900, 2, 40, dict(norm_tok=True, norm_byte=True, norm_out=True), 9213),    # K = 1920: 896 is not 256 n -> the strided kernel
 ])
 def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     kw = dict(kw)

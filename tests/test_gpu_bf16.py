@@ -439,6 +439,8 @@ def test_bf16_mean_backward_vs_oracle(mot, D, bpt, Vt, Vc, B, T, kw, seed):
     (64, 16, 8, 128, 512, 1, 77, dict(norm_tok=True, norm_out=True), 9804),      # token count not a multiple of 8: the fp32-MFMA backward route
     (64, 16, 8, 128, 512, 3, 40, dict(norm_byte=True), 9805),                    # no post-norm: dy is the upstream gradient itself
     (104, 24, 5, 384, 512, 2, 520, dict(norm_byte=True, norm_out=True, bytes_first=True), 9806),    # K = 224, Dm = 384: ragged dW tiles
+    (768, 64, 16, 1024, 900, 2, 48, dict(norm_tok=True, norm_byte=True, norm_out=True), 9807),      # the reference's dimension sweeps: K = 1792
+    (1024, 128, 16, 1024, 900, 2, 40, dict(norm_tok=True, norm_byte=True, norm_out=True), 9808),    # K = 3072
 ])
 def test_bf16_concat_backward_through_autograd(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     kw = dict(kw)
