@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kBwdThreads) void embed_mix_bwd_kernel(const BwdArg
 #pragma unroll
             for (int j = 0; j < NE; ++j) acc[j] = 0.f;
         }
-        const int64_t trow = (int64_t)tok * Dt, grow = n * D;
+        const int64_t trow = (int64_t)tok * Dt, grow = n * (int64_t)(A.g_ld ? A.g_ld : D);   // (g_ld: gradient rows that are columns of a wider matrix)
         float an[NE], bn[NE], dy[NE];
         // ---- gather (the same rows the forward read)
 #pragma unroll
@@ -1643,7 +1643,7 @@ static int run_scatter(BwdArgs &A, const MotEmbedMixDesc &d, int32_t *ws_ints, f
 #endif
     if (d.tok_rows >= (1 << 21) - 1)   // (token << 11 | index) of bwd_rank_kernel must stay below its 0xffffffff padding key
         return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd: token tables of %lld rows (>= 2^21 - 1) are not built", (long long)d.tok_rows);
-    const bool full = full_layout<MODE>(A);
+    const bool full = full_layout<MODE>(A) && !A.g_ld;   // (a row stride is known to the lane-contiguous kernel and to the general one)
     bool lc = false, plain = false;
     if constexpr (MODE != MOT_MIX_CONCAT_LINEAR) {
         lc = lc_layout<MODE>(A) && !(A.abl & 8);   // abl 8: dev switch back to the strided kernels
@@ -2498,7 +2498,8 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         int per = d.bpt;
         while (per > 1 && per * d.byte_dim > 1024) per = (per + 1) / 2;
         Ab.D = Ab.Dt = Ab.nbk = per * d.byte_dim;
-        bool split = lc_layout<MOT_MIX_NOOP>(At) && d.bpt % per == 0 && lc_layout<MOT_MIX_SUM>(Ab);
+        // (the token part: the lane-contiguous kernel, or -- 896 columns -- the general one, which knows the row stride too)
+        bool split = d.bpt % per == 0 && lc_layout<MOT_MIX_SUM>(Ab) && (lc_layout<MOT_MIX_NOOP>(At) || K > 2048);
 #ifdef MOT_DEV_ABLATION
         if (getenv("MOT_CONCAT_SCATTER_OLD")) split = false;
 #endif
@@ -2532,8 +2533,8 @@ static int launch_embed_mix_bwd_linear(const MotEmbedMixDesc &d, const MotEmbedM
         }
     }
     if (K > 2048)
-        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 2048 needs the part-wise scatter (one id tensor, no learned scalars, token part a "
-                         "multiple of 256 columns <= 1024, byte slots that tile blocks of <= 1024 columns)", K);
+        return set_error(MOT_EUNSUPPORTED, "embed_mix_bwd concat_linear: K %d > 2048 needs the part-wise scatter (one id tensor, no learned scalars, "
+                         "byte slots that tile blocks of <= 1024 columns)", K);
     return run_scatter<MOT_MIX_CONCAT_LINEAR>(A, d, sort_ints, rn, stream);
 }
 

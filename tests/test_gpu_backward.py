@@ -137,6 +137,7 @@ def test_mathblations_backward_vs_reference_autograd(mot):
     (768, 64, 16, 1024, 900, 2, 48, dict(norm_tok=True, norm_byte=True, norm_out=True), 9211),    # K = 1792: token part + one block of 16 slots
     (1024, 128, 16, 1024, 900, 2, 40, dict(norm_tok=True, norm_byte=True, norm_out=True), 9212),  # K = 3072: two blocks of 8 slots
     (896, 64, 16, 1024, 900, 2, 40, dict(norm_tok=True, norm_byte=True, norm_out=True), 9213),    # K = 1920: 896 is not 256 n -> the strided kernel
+    (896, 128, 16, 1024, 900, 2, 40, dict(norm_tok=True, norm_byte=True, norm_out=True), 9214),   # K = 2944: token part on the general kernel, two slot blocks
 ])
 def test_concat_backward_vs_oracle(mot, Dt, Db, bpt, Dm, Vt, B, T, kw, seed):
     kw = dict(kw)
