@@ -634,7 +634,9 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
     d.q_w, d.kv_w, d.proj_w, d.lambda_factor = capi.ptr(qw), capi.ptr(kvw), capi.ptr(pw), capi.ptr(lam)
     d.cos_q, d.sin_q, d.cos_k, d.sin_k = (capi.ptr(r) for r in rot)
     d.rot_q_len, d.rot_k_len = rot[0].shape[0], rot[2].shape[0]
-    d.eps = float(eps or 0.0)
+    # norm() is F.rms_norm(x, eps=None): eps = finfo(x.dtype).eps, and with bf16 tables every tensor it is applied to here (the
+    # embeddings, q, k) is bf16 in the reference -- 2^-7, not the float32 epsilon of the widened copies (train_gpt.py:172-173)
+    d.eps = float(eps or (2.0 ** -7 if bf else 0.0))
     d.status = capi.ptr(capi.status_word(dev))
     return d, [tok, tt, bt, qw, kvw, pw, lam, ia, ib] + rot, dev, T, D
 

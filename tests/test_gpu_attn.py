@@ -398,8 +398,12 @@ def test_cross_attn_bf16_tables_two_id_tensors(mot):
     used = lambda w: d64(orc.bf16_round(w))
     lam = float(orc.bf16_round(np.array([0.35]))[0])
     args = (toks[0], padded[0], pulled[0], d64(Et), d64(Eb), used(q_w), used(kv_w), used(p_w), lam, *[r.numpy() for r in rot])
-    ref = orc.cross_attn(*args, bpt=bpt, n_heads=H, dtype=np.float64, head_layout=0)
-    refg = orc.cross_attn_bwd(*args, d64(g), bpt=bpt, n_heads=H, norm_tok=True, norm_byte=True, head_layout=0)
+    orc.set_eps(2.0 ** -7)   # norm() on bf16 tensors: eps = finfo(bfloat16).eps
+    try:
+        ref = orc.cross_attn(*args, bpt=bpt, n_heads=H, dtype=np.float64, head_layout=0)
+        refg = orc.cross_attn_bwd(*args, d64(g), bpt=bpt, n_heads=H, norm_tok=True, norm_byte=True, head_layout=0)
+    finally:
+        orc.set_eps(0.0)
     P = lambda a, dt=None: torch.nn.Parameter(dev(a) if dt is None else dev(a).to(dt))
     pEt, pEb = P(Et, torch.bfloat16), P(Eb, torch.bfloat16)
     pq, pkv, pp, plam = P(q_w), P(kv_w), P(p_w), torch.nn.Parameter(torch.tensor(0.35, device=DEV))
@@ -442,8 +446,12 @@ def test_cross_attn_bf16_tables(mot, matmul, T):
     lam = float(orc.bf16_round(np.array([0.35]))[0])
     rots = [r.numpy() for r in rot]
     args = (toks[0], pulled[0], None, d64(Et), d64(Eb), used(q_w), used(kv_w), used(p_w), lam, *rots)
-    ref = orc.cross_attn(*args, bpt=bpt, n_heads=H, dtype=np.float64, head_layout=0)
-    refg = orc.cross_attn_bwd(*args, d64(g), bpt=bpt, n_heads=H, norm_tok=True, norm_byte=True, head_layout=0)
+    orc.set_eps(2.0 ** -7)   # norm() on bf16 tensors: eps = finfo(bfloat16).eps (what bf16 tables select in cross_attn)
+    try:
+        ref = orc.cross_attn(*args, bpt=bpt, n_heads=H, dtype=np.float64, head_layout=0)
+        refg = orc.cross_attn_bwd(*args, d64(g), bpt=bpt, n_heads=H, norm_tok=True, norm_byte=True, head_layout=0)
+    finally:
+        orc.set_eps(0.0)
     P = lambda a, dt=None: torch.nn.Parameter(dev(a) if dt is None else dev(a).to(dt))
     pEt, pEb = P(Et, torch.bfloat16), P(Eb, torch.bfloat16)
     pq, pkv, pp, plam = P(q_w), P(kv_w), P(p_w), torch.nn.Parameter(torch.tensor(0.35, device=DEV))
@@ -458,9 +466,13 @@ def test_cross_attn_bf16_tables(mot, matmul, T):
         assert (steps(want) <= 1).all() and (got == want).mean() > 0.97
     else:
         rows = d64(Et)[toks[0]]
-        xq = d64(orc.bf16_round(rows / np.sqrt((rows * rows).mean(axis=1, keepdims=True) + np.finfo(np.float32).eps)))
-        y = orc.cross_attn(np.arange(T), pulled[0], None, xq, d64(Eb), used(q_w), used(kv_w), np.eye(D), lam, *rots, bpt=bpt, n_heads=H,
-                           dtype=np.float64, head_layout=0, norm_tok=False)
+        xq = d64(orc.bf16_round(rows / np.sqrt((rows * rows).mean(axis=1, keepdims=True) + 2.0 ** -7)))
+        orc.set_eps(2.0 ** -7)
+        try:
+            y = orc.cross_attn(np.arange(T), pulled[0], None, xq, d64(Eb), used(q_w), used(kv_w), np.eye(D), lam, *rots, bpt=bpt, n_heads=H,
+                               dtype=np.float64, head_layout=0, norm_tok=False)
+        finally:
+            orc.set_eps(0.0)
         emul = orc.bf16_round(d64(orc.bf16_round(y)) @ used(p_w).T)
         assert (steps(emul) <= 1).all() and (got == emul).mean() > 0.97, (steps(emul).max(), (got == emul).mean())
         # (without the two roundings: they move an output by ~2^-9 of the TYPICAL size of the outputs, whatever its own size)
