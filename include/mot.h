@@ -413,7 +413,12 @@ typedef struct MotCharSwaDesc {
      * fp32 accumulation, xn and y rounded to bf16 first and the weights taken as bf16 (for callers whose tables and weights
      * hold bf16 values; the reference script runs in float32); needs dim % 8 == 0 and (heads * head_dim) % 8 == 0. */
     int32_t matmul_dtype;
-    int32_t reserved0;
+    /* 1 = `kv_tables` already holds this call's per-character key / value tables (skip building them) */
+    int32_t kv_tables_ready;
+    /* optional: caller-kept buffer of 2 * char_rows * n_heads * head_dim floats for the projected key / value rows of the character
+     * table.  They depend on char_table, char_norm_w, wk and wv only, so an inference loop (what the reference file is) builds them
+     * once: pass the buffer with kv_tables_ready = 0 after those change (the call fills it), = 1 otherwise. */
+    void *kv_tables;
 } MotCharSwaDesc;
 
 size_t mot_char_swa_desc_size(void);

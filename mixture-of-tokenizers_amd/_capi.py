@@ -117,7 +117,8 @@ class MotCharSwaDesc(C.Structure):
         ("char_table", C.c_void_p), ("char_rows", C.c_int32), ("norm_eps", C.c_float),
         ("attn_norm_w", C.c_void_p), ("char_norm_w", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p), ("wo", C.c_void_p),
         ("lambda_tok", C.c_void_p), ("lambda_char", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
-        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("matmul_dtype", C.c_int32), ("reserved0", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("matmul_dtype", C.c_int32), ("kv_tables_ready", C.c_int32),
+        ("kv_tables", C.c_void_p),
     ]
 
 

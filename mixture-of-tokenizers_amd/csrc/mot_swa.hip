@@ -181,13 +181,19 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
         if ((rc = launch_narrow((const float *)d.wq, (int64_t)hdim * d.dim, wq16, stream))) return rc;
         if ((rc = launch_narrow((const float *)d.wo, (int64_t)hdim * d.dim, wo16, stream))) return rc;
     }
+    if (d.kv_tables) {   // caller-kept key / value tables: built by this call unless it says they are current
+        kt = (float *)d.kv_tables;
+        vt = kt + (size_t)d.char_rows * hdim;
+    }
     // ---- per character-table row: normalise, project to keys and values
-    hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int64_t>, dim3((unsigned)((d.char_rows + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream,
-                       (const int64_t *)nullptr, (int64_t)d.char_rows, (const float *)d.char_table, (int64_t)d.char_rows, d.dim,
-                       (const float *)d.char_norm_w, eps, cn, d.status, kStatusByteOor);
-    if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
-    if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wk, d.dim, d.dim, hdim, kt, hdim, true, stream))) return rc;
-    if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wv, d.dim, d.dim, hdim, vt, hdim, true, stream))) return rc;
+    if (!(d.kv_tables && d.kv_tables_ready)) {
+        hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int64_t>, dim3((unsigned)((d.char_rows + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream,
+                           (const int64_t *)nullptr, (int64_t)d.char_rows, (const float *)d.char_table, (int64_t)d.char_rows, d.dim,
+                           (const float *)d.char_norm_w, eps, cn, d.status, kStatusByteOor);
+        if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
+        if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wk, d.dim, d.dim, hdim, kt, hdim, true, stream))) return rc;
+        if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wv, d.dim, d.dim, hdim, vt, hdim, true, stream))) return rc;
+    }
     const size_t lds = ((size_t)d.char_rows * (d.head_dim + 4) + (size_t)d.char_rows * d.head_dim + 2 * 64 * kSwaWaves) * sizeof(float);
     if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "char_swa: %d character rows x head_dim %d need %zu B of LDS (> 160 KiB)", d.char_rows, d.head_dim, lds);
     for (int64_t n0 = 0; n0 < N; n0 += slab) {

@@ -758,18 +758,22 @@ _SWA_VERSIONS = {"no_residual": capi.SWA_NO_RESIDUAL, "one_residual": capi.SWA_O
 def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tensor, char_table: torch.Tensor, *,
              attn_norm_w: torch.Tensor, char_norm_w: torch.Tensor, wq: torch.Tensor, wk: torch.Tensor, wv: torch.Tensor, wo: torch.Tensor,
              n_heads: int, head_dim: int, window: int = 8, norm_eps: float = 1e-5, version: str = "two_residual",
-             lambda_tok: torch.Tensor | None = None, lambda_char: torch.Tensor | None = None, matmul: str | None = None) -> torch.Tensor:
+             lambda_tok: torch.Tensor | None = None, lambda_char: torch.Tensor | None = None, matmul: str | None = None,
+             kv_cache: dict | None = None) -> torch.Tensor:
     """The Llama character mixer up to the feed-forward (inference.py:146-224 + 260-267 on the gathers of 323-327):
     tokens (B, T) int, char_ids (B, T, c_v) int64 -> h (B, T, dim) fp32.  bf16 tables: bf16 result; operands widened once, the
     attention in fp32, the two products over the tokens (wq, wo) on the bf16 MFMA with their row operands rounded to bf16
     (`matmul="fp32"` keeps them on the fp32 MFMA, `matmul="bf16"` asks for the bf16 MFMA with fp32 tables).  Forward only (the
-    file is the reference's inference path); see mot_char_swa_fwd in include/mot.h."""
+    file is the reference's inference path); see mot_char_swa_fwd in include/mot.h.  `kv_cache` (a dict the caller keeps, e.g. on
+    the module): the per-character key / value tables are reused across calls while char_table, char_norm_w, wk and wv are unchanged
+    (storage and version are checked)."""
     if matmul not in (None, "fp32", "bf16"):
         raise ValueError(f"char_swa: matmul must be None, 'fp32' or 'bf16' (got {matmul!r})")
     if tokens.ndim == 1:
         tokens, char_ids = tokens[None], char_ids[None]
     if char_ids.ndim != 3 or char_ids.shape[:2] != tokens.shape:
         raise ValueError(f"char_ids must be (B, T, c_v) matching tokens {tuple(tokens.shape)}, got {tuple(char_ids.shape)}")
+    kv_key = tuple((t.data_ptr(), t._version) for t in (char_table, char_norm_w, wk, wv)) + (float(norm_eps), str(char_table.dtype))
     params = (tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, lambda_tok, lambda_char)
     if torch.is_grad_enabled() and any(p is not None and p.requires_grad for p in params):
         raise RuntimeError("mixture-of-tokenizers_amd: the character mixer (inference/inference.py) is built forward-only; call it under "
@@ -811,6 +815,12 @@ def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tens
     out = torch.empty((B, T, D), dtype=f32, device=dev)
     d.out = capi.ptr(out)
     d.status = capi.ptr(capi.status_word(dev))
+    if kv_cache is not None:
+        n = 2 * ct.shape[0] * hdim
+        if kv_cache.get("buf") is None or kv_cache["buf"].numel() != n or kv_cache["buf"].device != dev:
+            kv_cache["buf"], kv_cache["key"] = torch.empty(n, dtype=f32, device=dev), None
+        d.kv_tables, d.kv_tables_ready = capi.ptr(kv_cache["buf"]), int(kv_cache.get("key") == kv_key + (str(dev),))
+        kv_cache["key"] = kv_key + (str(dev),)
     ws = _workspace(dev, capi.lib.mot_char_swa_workspace_bytes(C.byref(d)))
     if ws is not None:
         d.workspace, d.workspace_bytes = capi.ptr(ws), ws.numel()

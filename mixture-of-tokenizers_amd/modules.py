@@ -612,6 +612,7 @@ class TokenMixByCharBMMBlock(nn.Module):
         self.char_norm = RMSNorm(args.dim, eps=args.norm_eps)
         self.ffn_norm = RMSNorm(args.dim, eps=args.norm_eps)
         self.args, self.version = args, args.version
+        self._kv_cache: dict = {}   # per-character K / V tables of the mixer, kept across calls while their inputs are unchanged
         if self.version in ["two_residual", "no_residual"]:
             self.lambda_tok = nn.Parameter(torch.ones(1))
             self.lambda_char = nn.Parameter(torch.ones(1))
@@ -635,7 +636,8 @@ class TokenMixByCharBMMBlock(nn.Module):
         return F_mot.char_swa(tokens, cid, toks.tok_weight, chars.byte_weight, attn_norm_w=self.attention_norm.weight,
                               char_norm_w=self.char_norm.weight, wq=ta.wq.weight, wk=ta.wk.weight, wv=ta.wv.weight, wo=ta.wo.weight,
                               n_heads=ta.n_heads, head_dim=ta.head_dim, window=ta.window_size, norm_eps=self.attention_norm.eps,
-                              version=self.version, lambda_tok=self.lambda_tok if two else None, lambda_char=self.lambda_char if two else None)
+                              version=self.version, lambda_tok=self.lambda_tok if two else None, lambda_char=self.lambda_char if two else None,
+                              kv_cache=self._kv_cache)   # (forward-only path: the per-character K / V tables are kept while their inputs are unchanged)
 
     def forward(self, toks, chars, rotary_emb_fn=None) -> Tensor:
         h = self.mix(toks, chars)

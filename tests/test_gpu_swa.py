@@ -160,3 +160,23 @@ def test_char_swa_bf16_tables(mot, matmul, T):
             (em.max(), (em <= 1).mean())
         plain = oracle()   # without the two roundings: they move an output by ~2^-9 of the TYPICAL size of h, whatever its own size
         assert (np.abs(got - plain) <= 3 * 2.0 ** -8 * np.maximum(np.abs(plain), np.sqrt((plain ** 2).mean()))).all()
+
+
+def test_char_swa_kv_cache_reuses_and_refreshes(mot):
+    """`kv_cache`: the per-character key / value tables are built once and reused while char_table, char_norm_w, wk, wv are unchanged
+    (same result bit for bit, with the cached tables); an in-place change of any of them rebuilds the tables."""
+    B, T, c_v, d, H, hd, window = 2, 40, 8, 256, 4, 64, 8
+    c = case(23, B, T, c_v, d, H, hd, 500, 132)
+    t = {k: dev(v) for k, v in c.items()}
+    kw = dict(attn_norm_w=t["wa"], char_norm_w=t["wc"], wq=t["wq"], wk=t["wk"], wv=t["wv"], wo=t["wo"], n_heads=H, head_dim=hd, window=window,
+              version="no_residual")
+    cache = {}
+    ref = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], **kw)
+    a = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], kv_cache=cache, **kw)
+    key = cache["key"]
+    b = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], kv_cache=cache, **kw)      # tables reused
+    assert torch.equal(a, ref) and torch.equal(b, ref) and cache["key"] == key
+    t["wk"].mul_(1.5)                                                                              # in place: version changes
+    ref2 = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], **kw)
+    c2 = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], kv_cache=cache, **kw)
+    assert cache["key"] != key and torch.equal(c2, ref2) and not torch.equal(c2, ref)

@@ -12,6 +12,7 @@ import mixture_of_tokenizers_amd as mot
 
 B, T = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8, 8192)
 variant = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+cache = {} if (len(sys.argv) > 4 and sys.argv[4] == "kv-cache") else None   # inference: the per-character K / V tables kept across calls
 dev = torch.device("cuda", 0)
 d, H, hd, cv, Vt, Vc = 2048, 32, 64, 8, 128256, 132
 g = torch.Generator(device=dev).manual_seed(1)
@@ -28,9 +29,9 @@ if variant != "fp32":
     Et, Ec, wq, wk, wv, wo, wa, wc, lt, lc = (t.bfloat16() for t in (Et, Ec, wq, wk, wv, wo, wa, wc, lt, lc))
     matmul = "fp32" if variant == "bf16-fp32mm" else None
 step = lambda: mot.functional.char_swa(toks, cid, Et, Ec, attn_norm_w=wa, char_norm_w=wc, wq=wq, wk=wk, wv=wv, wo=wo, n_heads=H, head_dim=hd,
-                                       lambda_tok=lt, lambda_char=lc, matmul=matmul)
+                                       lambda_tok=lt, lambda_char=lc, matmul=matmul, kv_cache=cache)
 ms = bench.timed_launches(step, 10, warm=2)
 N = B * T
 flop = 2 * 2 * d * H * hd * N + 2 * 2 * 64 * hd * H * N          # q and o projections + 64 keys x (score, value) per head
-print(json.dumps({"variant": variant, "tokens": N, "ms": ms, "tokens_per_s": N / (ms * 1e-3), "dense_TFLOPs": flop / (ms * 1e-3) / 1e12,
+print(json.dumps({"variant": variant, "kv_cache": cache is not None, "tokens": N, "ms": ms, "tokens_per_s": N / (ms * 1e-3), "dense_TFLOPs": flop / (ms * 1e-3) / 1e12,
                   "note": "whole call: gather+RMSNorm, wq GEMM, 132-row K/V tables, char_swa_kernel, residual (MEAN kernel), wo GEMM"}))
