@@ -789,7 +789,20 @@ def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tens
     if bf:
         if char_table.dtype != torch.bfloat16:
             raise TypeError(f"char_swa: char_table is {char_table.dtype} but the token table is bfloat16")
-        widen = lambda t: None if t is None else t.detach().to(torch.bfloat16).float()
+        # (with `kv_cache` the widened copies are kept beside the tables while the originals are unchanged: the file is an inference
+        #  path, and the Llama token table alone is 0.5 GB to read and 1 GB to write per call otherwise)
+        wide_cache = None if kv_cache is None else kv_cache.setdefault("widened", {})
+
+        def widen(t):
+            if t is None:
+                return None
+            if wide_cache is None:
+                return t.detach().to(torch.bfloat16).float()
+            key = (t.data_ptr(), t._version, tuple(t.shape), str(t.dtype))
+            hit = wide_cache.get(id(t))
+            if hit is None or hit[0] != key:
+                hit = wide_cache[id(t)] = (key, t.detach().to(torch.bfloat16).float(), t)   # (t itself: the id stays its own)
+            return hit[1]
         tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, lambda_tok, lambda_char = (
             widen(t) for t in (tok_table, char_table, attn_norm_w, char_norm_w, wq, wk, wv, wo, lambda_tok, lambda_char))
     tt, ct = _contig(tok_table.detach(), f32, "tok_table"), _contig(char_table.detach(), f32, "char_table")
