@@ -578,7 +578,7 @@ def embed_mix(tokens: torch.Tensor, tok_table: torch.Tensor, byte_table: torch.T
 
 
 def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                     bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul=None, widened=None):
+                     bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul=None, widened=None, wide_cache=None):
     """Validated MotCrossAttnDesc for both directions; returns (desc, keepalive list, device, T, D).  `widened`: the fp32 copies
     (tables, weights, lambda) an earlier call of the same autograd node made of the same bf16 operands -- keep[1:7] -- reused
     instead of made again."""
@@ -600,6 +600,16 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
         raise TypeError(f"cross_attn: byte table is {byte_table.dtype} but the token table is {tok_table.dtype}")
     wide = (lambda t: t.detach().float()) if bf else (lambda t: t.detach())
     as_used = (lambda w: w.detach().to(torch.bfloat16).float()) if bf else (lambda w: w.detach())
+    if bf and wide_cache is not None:   # no-grad calls with a caller-kept cache: the fp32 copies live beside the K / V tables
+        def _kept(fn):
+            def get(t):
+                key = (t.data_ptr(), t._version, tuple(t.shape), str(t.dtype))
+                hit = wide_cache.get(id(t))
+                if hit is None or hit[0] != key:
+                    hit = wide_cache[id(t)] = (key, fn(t), t)
+                return hit[1]
+            return get
+        wide, as_used = _kept(wide), _kept(as_used)
     if widened is not None:   # (the backward of a bf16 step: the forward's copies; autograd has checked that the originals are unchanged)
         wide = as_used = None
         tt, bt = widened[0], widened[1]
@@ -700,7 +710,8 @@ def _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj
                     bpt, n_heads, norm_tok=True, norm_byte=True, head_layout="as_viewed", eps=None, kv_cache=None, saved_qy=None, matmul=None,
                     _keep_widened=None):
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
-                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul)
+                                          bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul,
+                                          wide_cache=None if kv_cache is None else kv_cache.setdefault("widened", {}))
     if _keep_widened is not None:
         _keep_widened.extend(keep[1:7])   # tt, bt, qw, kvw, pw, lam
     out = torch.empty((1, T, D), dtype=torch.float32, device=dev)
