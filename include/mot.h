@@ -341,6 +341,10 @@ typedef struct MotCrossAttnDesc {
      * fp32.  Needs dim % 8 == 0.  Workspace sizes depend on it. */
     int32_t matmul_dtype;
     int32_t reserved0;
+    /* optional, with matmul_dtype == MOT_BF16: the caller's bf16 token table [tok_rows, dim] whose widened copy `tok_table` is.
+     * The normalised token rows -- the row operand of W_q and of dW_q -- are then gathered in bf16 directly (the same values: norm
+     * in fp32, one rounding), without the fp32 detour. */
+    const void *tok_table_bf16;
 } MotCrossAttnDesc;
 
 /*

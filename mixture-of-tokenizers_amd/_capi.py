@@ -96,6 +96,7 @@ class MotCrossAttnDesc(C.Structure):
         ("rot_q_len", C.c_int64), ("rot_k_len", C.c_int64), ("eps", C.c_float), ("kv_tables_ready", C.c_int32),
         ("out", C.c_void_p), ("status", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("kv_tables", C.c_void_p), ("saved_qy", C.c_void_p), ("matmul_dtype", C.c_int32), ("reserved0", C.c_int32),
+        ("tok_table_bf16", C.c_void_p),
     ]
 
 

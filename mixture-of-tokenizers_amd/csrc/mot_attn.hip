@@ -33,6 +33,7 @@ constexpr int kHd = 128;  // head_dim of every CrossAttention the reference buil
 struct AttnArgs {
     const float *q;       // [T, HD] projected queries
     float *y;             // [T, HD]
+    __bf16 *y16;          // optional: y once more in bf16 (the row operand of c_proj on the bf16 MFMA: no narrowing pass)
     const float *kt, *vt; // [rows, HD]: per byte-table row (ids != null) or per kv position (ids == null)
     const int64_t *ids;   // [T*bpt] byte ids or null
     int64_t rows;
@@ -140,6 +141,10 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
     float *yp = A.y + t * HD + h * kHd;
     yp[lane] = y0;
     yp[64 + lane] = y1;
+    if (A.y16) {
+        A.y16[t * HD + h * kHd + lane] = (__bf16)y0;
+        A.y16[t * HD + h * kHd + 64 + lane] = (__bf16)y1;
+    }
 }
 
 
@@ -204,10 +209,17 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     int rc;
     // 1. q = W_q norm?(E_t[tok])          (train_gpt.py:348-377 + 277): seam gather, then the plain dense MFMA kernel
     float *xq = D > HD ? ws + L.xq : y;
-    if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, (int)D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
-        return rc;
-    if (mm16(d)) rc = dense_rows_bf16(xq, T, D, (const float *)d.q_w, HD, q, ws + L.a16, ws + L.w16, stream);
-    else rc = launch_gemm_rows(xq, (int)D, T, (const float *)d.q_w, (int)D, (int)D, (int)HD, q, (int)HD, true, stream);
+    if (mm16(d) && d.tok_table_bf16) {   // the caller's bf16 table: the normalised rows come out in bf16 directly (the same roundings, two passes less)
+        if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table_bf16, d.tok_rows, (int)D, d.norm_tok, eps, nullptr, ws + L.a16, d.status, MOT_BF16,
+                                     stream))) return rc;
+        if ((rc = launch_narrow((const float *)d.q_w, (int64_t)HD * D, ws + L.w16, stream))) return rc;
+        rc = launch_gemm_rows_bf16(ws + L.a16, D, T, ws + L.w16, D, D, HD, q, HD, false, nullptr, stream);
+    } else {
+        if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, (int)D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
+            return rc;
+        if (mm16(d)) rc = dense_rows_bf16(xq, T, D, (const float *)d.q_w, HD, q, ws + L.a16, ws + L.w16, stream);
+        else rc = launch_gemm_rows(xq, (int)D, T, (const float *)d.q_w, (int)D, (int)D, (int)HD, q, (int)HD, true, stream);
+    }
     if (rc) return rc;
     // 2. key/value rows: per byte-table row, or per kv position when the embedding is norm(E[a] + E[b])
     const int kv_norm = d.norm_byte;
@@ -241,11 +253,15 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     AttnArgs A;
     A.q = q; A.y = y; A.kt = kt; A.vt = vt; A.ids = dual ? nullptr : d.ids_a; A.rows = L.R; A.T = T; A.bpt = d.bpt; A.H = H;
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
+    A.y16 = mm16(d) ? (__bf16 *)(ws + L.a16) : nullptr;   // (the row operand of q has been consumed: stream order)
     const int64_t waves = T * H;
     hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
     if ((rc = check_launch("cross_attn_kernel"))) return rc;
     // 4. out = c_proj y                   (line 293): out[t][c] = sum_r y[t][r] * proj_w[c][r]
-    if (mm16(d)) return dense_rows_bf16(y, T, HD, (const float *)d.proj_w, D, (float *)d.out, ws + L.a16, ws + L.w16, stream);
+    if (mm16(d)) {
+        if ((rc = launch_narrow((const float *)d.proj_w, (int64_t)D * HD, ws + L.w16, stream))) return rc;
+        return launch_gemm_rows_bf16(ws + L.a16, HD, T, ws + L.w16, HD, HD, D, d.out, D, false, nullptr, stream);
+    }
     return launch_gemm_rows(y, (int)HD, T, (const float *)d.proj_w, (int)HD, (int)HD, (int)D, (float *)d.out, (int)D, true, stream);
 }
 
@@ -277,6 +293,7 @@ struct AttnBwdArgs {
     const float *cos_q, *sin_q, *cos_k, *sin_k;
     float eps;
     float *dq;
+    __bf16 *dq16;      // when given, dq is written here in bf16 INSTEAD (it is only ever the row operand of two bf16 products)
     float *pw, *dsw;   // [T, H, bpt]: softmax weight and score gradient of every (token, head, key)
     float *qrot;       // [T, HD]: the normalised, rotated queries
 };
@@ -379,6 +396,11 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     // q: rope^T, head-norm^T
     const float dn0 = dq0 * cq - dq1 * sq, dn1 = dq0 * sq + dq1 * cq;
     const float m = wave_sum(dn0 * qn0 + dn1 * qn1) / (float)kHd;
+    if (A.dq16) {
+        A.dq16[t * HD + h * kHd + lane] = (__bf16)(rq * (dn0 - qn0 * m));
+        A.dq16[t * HD + h * kHd + 64 + lane] = (__bf16)(rq * (dn1 - qn1 * m));
+        return;
+    }
     float *o = A.dq + t * HD + h * kHd;
     o[lane] = rq * (dn0 - qn0 * m);
     o[64 + lane] = rq * (dn1 - qn1 * m);
@@ -609,7 +631,7 @@ __global__ __launch_bounds__(kThreads) void iota_i32_kernel(int32_t *__restrict_
 
 // workspace of the backward, in floats
 struct AttnBwdLayout {
-    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, ids32b, emb, emb_bytes, b0, b1, w16, x16, total;
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, ids32b, emb, emb_bytes, b0, b1, w16, x16, dq16, total;
 };
 static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
     memset(&e, 0, sizeof(e));
@@ -644,6 +666,7 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     const size_t b1n = dual && P * 2 * HD > T * wide ? P * 2 * HD : T * wide;
     L.b0 = take(mm16(d) ? (T * wide + 1) / 2 : 0); L.b1 = take(mm16(d) ? (b1n + 1) / 2 : 0); L.w16 = take(mm16(d) ? ((dual ? 2 : 1) * HD * D + 1) / 2 : 0);
     L.x16 = take(mm16(d) && dual ? (P * D + 1) / 2 : 0);
+    L.dq16 = take(mm16(d) ? (T * HD + 1) / 2 : 0);   // dq in bf16, written by the attention backward (b1 is reused for dkv in between)
     L.total = o;
     return L;
 }
@@ -716,6 +739,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     AttnArgs A;
     A.q = q; A.y = y; A.kt = kn; A.vt = vl; A.ids = dual ? nullptr : d.ids_a; A.rows = R; A.T = T; A.bpt = d.bpt; A.H = H;
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
+    A.y16 = nullptr;
     const int64_t waves = T * H;
     if (!d.saved_qy) {
         hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
@@ -742,6 +766,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     B.q_pre = q; B.dy = dy; B.kn = kn; B.vpre = vpre; B.lambda = d.lambda_factor; B.ids = dual ? nullptr : d.ids_a; B.rows = R; B.T = T; B.bpt = d.bpt; B.H = H;
     B.layout = d.head_layout; B.cos_q = d.cos_q; B.sin_q = d.sin_q; B.cos_k = d.cos_k; B.sin_k = d.sin_k; B.eps = eps;
     B.dq = dq; B.pw = pw; B.dsw = dsw; B.qrot = qrot;
+    B.dq16 = mm16(d) ? (__bf16 *)(ws + L.dq16) : nullptr;
     hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
     if ((rc = check_launch("cross_attn_bwd_kernel"))) return rc;
     // ---- per byte-table row: the sums over the kv positions of every byte id, from the grouped positions
@@ -821,19 +846,24 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         if ((rc = check_launch("byte_rows_bwd_kernel"))) return rc;
     }
     // ---- q_w and the token table
-    if (mm16(d) && (gr.d_q_w || gr.d_tok_table) && (rc = launch_narrow(dq, T * HD, b1, stream))) return rc;
+    // (mm16: dq arrived in bf16, straight from the attention backward)
     if (gr.d_q_w) {
-        if (!have_xq && (rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32, stream)))
-            return rc;
-        if (mm16(d)) {
-            if ((rc = launch_narrow(xq, T * D, b0, stream))) return rc;
-            if ((rc = launch_gemm_tn_bf16(b1, HD, HD, b0, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
-        } else if ((rc = launch_gemm_tn(dq, HD, HD, xq, D, D, T, (float *)gr.d_q_w, D, stream))) return rc;
+        if (mm16(d) && d.tok_table_bf16 && !have_xq) {   // the normalised token rows in bf16 directly from the caller's bf16 table
+            if ((rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table_bf16, d.tok_rows, D, d.norm_tok, eps, nullptr, b0, d.status, MOT_BF16, stream)))
+                return rc;
+        } else {
+            if (!have_xq && (rc = launch_gather_rows(d.tokens, nullptr, 4, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, nullptr, xq, d.status, MOT_F32,
+                                                     stream))) return rc;
+            if (mm16(d) && (rc = launch_narrow(xq, T * D, b0, stream))) return rc;
+        }
+        if (mm16(d)) rc = launch_gemm_tn_bf16((const __bf16 *)(ws + L.dq16), HD, HD, b0, D, D, T, (float *)gr.d_q_w, D, stream);
+        else rc = launch_gemm_tn(dq, HD, HD, xq, D, D, T, (float *)gr.d_q_w, D, stream);
+        if (rc) return rc;
     }
     if (gr.d_tok_table) {
         if (mm16(d)) {
             if ((rc = launch_narrow_transpose((const float *)d.q_w, HD, D, w16, stream))) return rc;   // [D][HD]
-            if ((rc = launch_gemm_rows_bf16(b1, HD, T, w16, HD, HD, D, dxq, D, false, nullptr, stream))) return rc;
+            if ((rc = launch_gemm_rows_bf16(ws + L.dq16, HD, T, w16, HD, HD, D, dxq, D, false, nullptr, stream))) return rc;
         } else if ((rc = dense_gemm_kmajor(dq, T, HD, (const float *)d.q_w, D, dxq, stream))) return rc;   // q_w [HD, D]
         noop_bwd_desc(ed, d.tokens, T, d.tok_table, d.tok_rows, D, d.norm_tok, eps, d.status);
         ed.workspace = emb_ws; ed.workspace_bytes = L.emb_bytes;

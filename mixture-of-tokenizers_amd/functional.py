@@ -637,6 +637,10 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
     d.struct_size = C.sizeof(capi.MotCrossAttnDesc)
     d.dtype, d.n_tokens, d.bpt, d.n_heads, d.dim = capi.F32, T, int(bpt), int(n_heads), D
     d.matmul_dtype = capi.BF16 if mm_bf16 else capi.F32
+    tt16 = None
+    if bf and mm_bf16:   # the bf16 table itself: the normalised token rows are then gathered in bf16 directly
+        tt16 = _contig(tok_table.detach(), torch.bfloat16, "tok_table")
+        d.tok_table_bf16 = capi.ptr(tt16)
     d.head_layout = {"as_viewed": capi.HEADS_AS_VIEWED, "per_token": capi.HEADS_PER_TOKEN}[head_layout]
     d.tokens, d.ids_a, d.ids_b = capi.ptr(tok), capi.ptr(ia), capi.ptr(ib)
     d.tok_table, d.tok_rows, d.byte_table, d.byte_rows = capi.ptr(tt), tt.shape[0], capi.ptr(bt), bt.shape[0]
@@ -648,7 +652,7 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
     # embeddings, q, k) is bf16 in the reference -- 2^-7, not the float32 epsilon of the widened copies (train_gpt.py:172-173)
     d.eps = float(eps or (2.0 ** -7 if bf else 0.0))
     d.status = capi.ptr(capi.status_word(dev))
-    return d, [tok, tt, bt, qw, kvw, pw, lam, ia, ib] + rot, dev, T, D
+    return d, [tok, tt, bt, qw, kvw, pw, lam, ia, ib] + rot + [tt16], dev, T, D
 
 
 class _CrossAttnFn(torch.autograd.Function):
