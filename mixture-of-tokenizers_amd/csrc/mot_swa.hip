@@ -30,7 +30,7 @@ namespace mot {
 template <typename IdT>
 __global__ __launch_bounds__(kThreads) void rows_rmsnorm_w_kernel(const IdT *__restrict__ ids, int64_t n, const float *__restrict__ table, int64_t rows,
                                                                   int dim, const float *__restrict__ weight, float eps, float *__restrict__ out,
-                                                                  uint32_t *status, uint32_t oor_flag) {
+                                                                  uint32_t *status, uint32_t oor_flag, __bf16 *__restrict__ out16 = nullptr) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
     if (r >= n) return;
@@ -51,7 +51,9 @@ __global__ __launch_bounds__(kThreads) void rows_rmsnorm_w_kernel(const IdT *__r
     const float rs = 1.0f / sqrtf(ss / (float)dim + eps);       // torch.rsqrt(x.pow(2).mean(-1) + eps), correctly rounded pieces
     for (int j = lane; j < nv; j += 64) {
         const float4v v = *(const float4v *)(p + 4 * j), w = *(const float4v *)(weight + 4 * j);
-        *(float4v *)(o + 4 * j) = (v * rs) * w;
+        const float4v x = (v * rs) * w;
+        if (out16) Elem<__bf16>::store4_nt(out16 + r * dim + 4 * j, x);   // the row operand of a bf16 product: written in bf16 INSTEAD
+        else *(float4v *)(o + 4 * j) = x;
     }
 }
 
@@ -69,7 +71,8 @@ constexpr int kSwaThreads = 512, kSwaWaves = kSwaThreads / 64;   // 8 waves shar
 template <int HDL>   // head_dim = 64 * HDL
 __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__restrict__ q, const float *__restrict__ ktab, const float *__restrict__ vtab,
                                                             const int64_t *__restrict__ char_ids, int64_t n0, int64_t n_tok, int64_t T, int c_v, int window,
-                                                            int char_rows, int n_heads, int tile_tokens, float *__restrict__ y, uint32_t *status) {
+                                                            int char_rows, int n_heads, int tile_tokens, float *__restrict__ y, uint32_t *status,
+                                                            __bf16 *__restrict__ y16) {   // y16: y is written there in bf16 instead (row operand of wo on the bf16 MFMA)
     constexpr int HD = 64 * HDL, KS = HD + 4;                    // key rows padded by 16 bytes: lanes reading different rows spread over the banks
     constexpr int QUADS = HD / 4, GROUPS = 64 / QUADS;           // 16 x 4 at head_dim 64, 32 x 2 at 128
     extern __shared__ __attribute__((aligned(16))) float lds_kv[];
@@ -139,7 +142,10 @@ __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__re
             acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
             acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
         }
-        if (lane < QUADS) *(float4v *)(y + tl * HDIM + h * HD + 4 * dq) = acc;
+        if (lane < QUADS) {
+            if (y16) Elem<__bf16>::store4_nt(y16 + tl * HDIM + h * HD + 4 * dq, acc);
+            else *(float4v *)(y + tl * HDIM + h * HD + 4 * dq) = acc;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is rewritten for the wave's next token
         __builtin_amdgcn_wave_barrier();
     }
@@ -201,10 +207,10 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
         float *out = (float *)d.out + n0 * d.dim;
         // ---- queries: gather + RMSNorm, then the projection
         hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int32_t>, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.tokens + n0, nn,
-                           (const float *)d.tok_table, d.tok_rows, d.dim, (const float *)d.attn_norm_w, eps, xn, d.status, kStatusTokenOor);
+                           (const float *)d.tok_table, d.tok_rows, d.dim, (const float *)d.attn_norm_w, eps, xn, d.status, kStatusTokenOor,
+                           mm16 ? (__bf16 *)a16 : nullptr);
         if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
-        if (mm16) {
-            if ((rc = launch_narrow(xn, nn * d.dim, a16, stream))) return rc;
+        if (mm16) {   // (the normalised rows and, below, the attention output arrive in bf16: no narrowing passes)
             if ((rc = launch_gemm_rows_bf16(a16, d.dim, nn, wq16, d.dim, d.dim, hdim, qb, hdim, false, nullptr, stream))) return rc;
         } else if ((rc = launch_gemm_rows(xn, d.dim, nn, (const float *)d.wq, d.dim, d.dim, hdim, qb, hdim, true, stream))) return rc;
         // ---- attention
@@ -214,12 +220,12 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
             static std::atomic<uint64_t> lds_ok{0};
             if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<1>, lds_ok, "char_swa_kernel"))) return rc;
             hipLaunchKernelGGL(char_swa_kernel<1>, grid, dim3(kSwaThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
-                               d.char_rows, d.n_heads, tile, yb, d.status);
+                               d.char_rows, d.n_heads, tile, yb, d.status, mm16 ? (__bf16 *)a16 : nullptr);
         } else {
             static std::atomic<uint64_t> lds_ok{0};
             if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<2>, lds_ok, "char_swa_kernel"))) return rc;
             hipLaunchKernelGGL(char_swa_kernel<2>, grid, dim3(kSwaThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
-                               d.char_rows, d.n_heads, tile, yb, d.status);
+                               d.char_rows, d.n_heads, tile, yb, d.status, mm16 ? (__bf16 *)a16 : nullptr);
         }
         if ((rc = check_launch("char_swa_kernel"))) return rc;
         // ---- residuals first (they overwrite `out`), then out += wo y
@@ -245,7 +251,6 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
             accumulate = true;
         }
         if (mm16) {
-            if ((rc = launch_narrow(yb, nn * hdim, a16, stream))) return rc;
             if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, out, d.dim, false, nullptr, stream, accumulate))) return rc;
         } else if ((rc = launch_gemm_rows(yb, hdim, nn, (const float *)d.wo, hdim, hdim, d.dim, out, d.dim, true, stream, nullptr, accumulate))) return rc;
     }
