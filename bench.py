@@ -568,7 +568,10 @@ def main(argv=None):
                                           ("gemm_rows_bt_kernel" if args.dtype == "f32" else "gemm_rows_bf16_kernel") +
                                           " + rows_rms_inplace (whole call)"),
                                "kernel_ms": kernel_ms, "flop_per_token": 2 * K * D, "tokens_per_launch": tokens_per_step}
-        if args.backward and mode == "sum":
+        # the backward record: on request, and with the headline line itself (one GPU, default workload, secondary records not
+        # switched off) so that the driver's own run carries it
+        want_bwd = args.backward or (world == 1 and wl == "c4" and args.ids == "fused" and not args.uniform_ids and not args.no_extra)
+        if want_bwd and mode == "sum":
             from mixture_of_tokenizers_amd import data_creation as dc
             F = mot.functional
             ids_b = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
