@@ -329,6 +329,28 @@ def extra_records(mot, device, dtype, steps, warmup):
                       "tokens_per_launch": rows * T, "why": why}
         del inp, tt, bt, out, plan
         torch.cuda.empty_cache()
+    if dtype == "f32":   # the production dtype beside the fp32 headline: forward and backward of the same batch with bf16 tables and output
+        from mixture_of_tokenizers_amd import data_creation as dc
+        B, T, vocab, bpt, D, Db, Vb, mode = WORKLOADS["c4"][:8]
+        inp = make_inputs("c4", device, seed=12345, uniform=False)
+        tt, bt = inp["tok_table"].bfloat16(), inp["byte_table"].bfloat16()
+        toks, tab = torch.from_numpy(inp["toks"]).to(device), torch.from_numpy(inp["tab"]).to(device)
+        out = torch.empty((B, T, D), dtype=torch.bfloat16, device=device)
+        plan = mot.embed_mix_plan(toks, tt, bt, mode="sum", bpt=bpt, ttb=tab, pull="left", norm_out=True, out=out)
+        ms = timed_launches(plan, steps, warm=warmup)
+        gbs = algorithmic_bytes_per_token("c4", "fused", 2) * B * T / (ms * 1e-3) / 1e9
+        F = mot.functional
+        ids = dc.pull_from_left(dc.tokens_to_bytes(toks, tab), bpt, 456, 457)
+        into = {"tok_table": torch.zeros_like(tt, dtype=torch.float32), "byte_table": torch.zeros_like(bt, dtype=torch.float32)}
+        order = F.token_order(toks, tt.shape[0])
+        gout = torch.randn_like(out)
+        bms = timed_launches(lambda: F.embed_mix_backward(gout, toks, tt, bt, token_order=order, mode="sum", bpt=bpt, ids_a=ids, norm_out=True, into=into),
+                             max(1, steps // 4), warm=3)
+        recs["c4_bf16_tables"] = {"kernel_ms": ms, "tokens_per_s": B * T / (ms * 1e-3), "achieved_GBps": gbs, "frac": gbs / HBM_PEAK_GBS,
+                                  "tokens_per_launch": B * T, "backward_kernel_ms": bms,
+                                  "why": "bf16 tables and output (train_gpt.py:1124-1126): algorithmic bytes with 2-byte elements; backward with the token order given"}
+        del inp, tt, bt, out, plan, into, gout
+        torch.cuda.empty_cache()
     return recs
 
 
