@@ -89,7 +89,14 @@ __device__ __forceinline__ void c16_barrier() {
 }
 
 // NS stages of W in LDS (NS - 1 steps of DMA in flight), ONE stage of the gathered operand (its next step waits in registers)
-template <int MT, int NT, int NS>
+#define C16_PASS_BEGIN for (int hh = 0; hh < NH; ++hh) {
+#define C16_PASS_END }
+// NH: column passes.  model_dim 1024 does not fit a 128-token tile's accumulators (256 registers); as 64-token tiles it streamed all
+// of W per 64 tokens and paid 8 DMA instructions per 16 MFMAs.  NH = 2 keeps the 128-token tile and computes its columns in two
+// passes of 512 (the tile's ids, rms factors and token-row norms are made once; the gathered operand is walked twice, out of L2):
+// pass 0 stores y un-normalised and keeps each row's sum of squares, pass 1 completes the sum, stores its half normalised and
+// rescales the first half in place (every lane re-reads exactly the pieces it wrote).
+template <int MT, int NT, int NS, int NH = 1>
 __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Args P) {
     constexpr int BM = 64 * MT, BN = 128 * NT, WMR = 32 * MT, WNR = 32 * NT, PD = NS - 1;
     constexpr int kStageB = BN * 64, kStageA = BM * 64, kDma = BN * 4 / kC16Threads;
@@ -98,6 +105,7 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     char *sA = lds_c + NS * kStageB;
     uint16_t *sIds = (uint16_t *)(sA + kStageA);                                  // [BM * bpt]
     float *sRn = (float *)(lds_c + NS * kStageB + kStageA + ((BM * P.bpt * 2 + 15) & ~15));   // [byte_rows] rms factors of the byte rows (1 when that part is not normalised)
+    float *sSS = sRn + P.byte_rows;                                               // [BM] (NH = 2) a row's sum of squares over the first column pass
     const uint32_t oB = lds_off(lds_c), oA = lds_off(sA), oIds = lds_off(sIds), oRn = lds_off(sRn);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, li = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,12 +125,13 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     }
     C16_STAMP(0);
     const int nsteps = K / 32;
+    const char *Wb = (const char *)P.W;   // the W rows of the current column pass
     auto b_request = [&](int s) {   // (a step past the end re-reads the last one into a stage nobody reads: the loop stays branch-free)
         char *sB = lds_c + (s % NS) * kStageB;
         const uint32_t ko = 64u * (uint32_t)min(s, nsteps - 1);
 #pragma unroll
         for (int i = 0; i < kDma; ++i) {
-            const char *g = (const char *)P.W + (goff[i] + ko);
+            const char *g = Wb + (goff[i] + ko);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                              (__attribute__((address_space(3))) void *)(sB + (i * 8 + wave) * 1024), 16, 0, 0);
         }
@@ -253,12 +262,6 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
         *(__attribute__((address_space(3))) bf16x8c *)(uintptr_t)a_dst = v;
     };
     f32x16c acc[MT][NT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     // fragment addresses: row = (wm | wn) + 32 t + li, piece (2 kk + h) ^ (row >> 2): the tile index t only adds t * 2048, kk flips bit 5
     const uint32_t fa0 = oA + (wm + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
     const uint32_t fb0 = (wn + li) * 64 + ((h ^ (li >> 2)) & 3) * 16;
@@ -266,11 +269,30 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     float r0_scale = 1.f, r1_scale = 1.f;
     constexpr bool kAllGather = BM * 4 == kC16Threads;   // every thread carries a piece: no branch around the requests
     constexpr int kInflight = PD == 2 ? kDma + 1 : 0;
+    const int ak_first = ak, slot_first = slot, within_first = within;
+    C16_PASS_BEGIN
+    if (NH > 1 && hh > 0) {   // the next column pass: its rows of W, the walk over the gathered operand from the start
+        __syncthreads();      // every wave is done with the staging area of the previous pass (it lies in the stages of W)
+        Wb = (const char *)P.W + (size_t)hh * BN * K * 2;
+        b_request(0);
+        if (PD == 2) b_request(1);
+        ak = ak_first; slot = slot_first; within = within_first;
+    }
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     if (kAllGather || a_thread) {
         a_request(r0_raw, r0_scale);
         if (PD == 2) a_request(r1_raw, r1_scale);
         asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r0_raw) : "n"(PD - 1) : "memory");
         a_commit(r0_raw, r0_scale);
+    }
+    if (NH > 1 && hh > 0) {   // (pass 0: the barrier of the prologue) this wave's DMA of the first stages is older than the piece it just
+        if (!(kAllGather || a_thread)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waited for; every wave's must have landed
+        c16_barrier();
     }
     // ---- the step.  One wave's share of step s is NP = 2 NT "positions" (kk, b) of MT MFMAs each; all eight waves run in lockstep
     // between the two barriers of a step, so whatever is not an MFMA has to be issued BETWEEN MFMAs or the matrix pipes idle:
@@ -291,7 +313,7 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     auto dma_piece = [&](int s, auto ic) {
         constexpr int i = decltype(ic)::value;
         char *sB = lds_c + (s % NS) * kStageB;
-        const char *g = (const char *)P.W + (goff[i] + 64u * (uint32_t)min(s, nsteps - 1));
+        const char *g = Wb + (goff[i] + 64u * (uint32_t)min(s, nsteps - 1));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                          (__attribute__((address_space(3))) void *)(sB + (i * 8 + wave) * 1024), 16, 0, 0);
     };
@@ -350,9 +372,10 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
     // y = bf16(acc + bias): F.linear on bf16 operands returns a bf16 tensor (train_gpt.py:185-186); norm() upcasts it (172-173, 443).
     // The tile leaves through LDS in halves of 32 MT rows (they fit in the stages of W): a lane packs its NT consecutive outputs of a
     // row; then 32 lanes take a row, sum its squares, scale and store whole 16-byte pieces.
+    const int cb = NH > 1 ? hh * BN : 0;   // first output column of this pass
     float bv[NT];
 #pragma unroll
-    for (int b = 0; b < NT; ++b) bv[b] = P.bias ? (float)P.bias[wn + li * NT + b] : 0.f;
+    for (int b = 0; b < NT; ++b) bv[b] = P.bias ? (float)P.bias[cb + wn + li * NT + b] : 0.f;
     __syncthreads();   // every wave is done with the last step's tiles
     C16_STAMP(5);
     __bf16 *stage = (__bf16 *)lds_c;   // [WMR][BN]
@@ -389,39 +412,65 @@ __global__ __launch_bounds__(kC16Threads) void concat16_gemm_kernel(const C16Arg
                 for (int e = 0; e < 8; ++e) ss += (float)v[p][e] * (float)v[p][e];
             }
             float rs = 1.f;
+            const bool first_of_two = NH > 1 && hh + 1 < NH;   // the row's other columns are still to come: no factor yet
             if (P.norm_out) {
 #pragma unroll
                 for (int o = 1; o < 32; o <<= 1) ss += __shfl_xor(ss, o, 64);
-                rs = rms_scale(ss, P.Dm, P.eps);
-                if (P.row_rnorm && li == 0 && row < nrows) P.row_rnorm[j0 + row] = rs;
+                if (first_of_two) {
+                    if (li == 0) sSS[row] = ss;
+                } else {
+                    if (NH > 1) ss += sSS[row];
+                    rs = rms_scale(ss, P.Dm, P.eps);
+                    if (P.row_rnorm && li == 0 && row < nrows) P.row_rnorm[j0 + row] = rs;
 #pragma unroll
-                for (int p = 0; p < PP; ++p)
+                    for (int p = 0; p < PP; ++p)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[p][e] = (__bf16)((float)v[p][e] * rs);
+                        for (int e = 0; e < 8; ++e) v[p][e] = (__bf16)((float)v[p][e] * rs);
+                }
             }
             if (row < nrows) {
+                __bf16 *orow = P.out + (j0 + row) * (int64_t)P.Dm + cb;
 #pragma unroll
-                for (int p = 0; p < PP; ++p)
-                    __builtin_nontemporal_store(v[p], (bf16x8c *)(P.out + (j0 + row) * (int64_t)P.Dm + 8 * (li + 32 * p)));
+                for (int p = 0; p < PP; ++p) {
+                    if (first_of_two && P.norm_out) *(bf16x8c *)(orow + 8 * (li + 32 * p)) = v[p];   // (comes back in the last pass: keep it in L2)
+                    else __builtin_nontemporal_store(v[p], (bf16x8c *)(orow + 8 * (li + 32 * p)));
+                }
+                if (NH > 1 && !first_of_two && P.norm_out) {
+                    // the first pass's columns of this row, un-normalised so far: this lane re-reads the pieces IT stored (device-scope
+                    // loads: not through this CU's L1) and rescales them
+                    for (int c0 = 0; c0 < cb; c0 += BN)
+#pragma unroll
+                        for (int p = 0; p < PP; ++p) {
+                            uint32_t *q = (uint32_t *)(orow - cb + c0 + 8 * (li + 32 * p));
+                            i32x4c w;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) w[e] = (int)__hip_atomic_load(q + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            bf16x8c u = __builtin_bit_cast(bf16x8c, w);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) u[e] = (__bf16)((float)u[e] * rs);
+                            __builtin_nontemporal_store(u, (bf16x8c *)q);
+                        }
+                }
             }
         }
         if (half == 0) c16_barrier();   // the staging area is rewritten
         C16_STAMP(6 + half);
     }
+    C16_PASS_END
 }
 
 static size_t c16_lds_base(int MT, int NT, int NS, int bpt);
-template <int MT, int NT, int NS>
+template <int MT, int NT, int NS, int NH = 1>
 static int launch_c16(const C16Args &P0, hipStream_t stream) {
     constexpr int BM = 64 * MT;
     const C16Args &P = P0;
-    const size_t lds = c16_lds_base(MT, NT, NS, P.bpt) + (size_t)P.byte_rows * 4;
+    const size_t lds = c16_lds_base(MT, NT, NS, P.bpt) + (size_t)P.byte_rows * 4 + (NH > 1 ? BM * 4 : 0);
     if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "concat16: needs %zu B of LDS", lds);
     static std::atomic<uint64_t> ok{0};
-    if (int rc = ensure_max_dyn_lds((const void *)concat16_gemm_kernel<MT, NT, NS>, ok, "concat16_gemm_kernel")) return rc;
+    if (int rc = ensure_max_dyn_lds((const void *)concat16_gemm_kernel<MT, NT, NS, NH>, ok, "concat16_gemm_kernel")) return rc;
     const int64_t blocks = (P.n + BM - 1) / BM;
     if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "concat16: too many rows");
-    hipLaunchKernelGGL((concat16_gemm_kernel<MT, NT, NS>), dim3((unsigned)blocks), dim3(kC16Threads), lds, stream, P);
+    hipLaunchKernelGGL((concat16_gemm_kernel<MT, NT, NS, NH>), dim3((unsigned)blocks), dim3(kC16Threads), lds, stream, P);
 #ifdef C16_STAMPS
     static int calls = 0;
     if (++calls == 60) {
@@ -507,13 +556,19 @@ int launch_wave_ids16(const MotEmbedMixDesc &d, uint16_t *ids16, hipStream_t str
 static size_t c16_lds_base(int MT, int NT, int NS, int bpt) {
     return (size_t)NS * 128 * NT * 64 + (size_t)64 * MT * 64 + (((size_t)64 * MT * bpt * 2 + 15) & ~(size_t)15);
 }
-struct C16Shape { int MT, NT, NS; };
+struct C16Shape { int MT, NT, NS, NH; };
+static bool c16_two_pass() {   // model_dim 1024 as two column passes of a 128-token tile (dev builds can switch back to 64-token tiles)
+#ifdef MOT_DEV_ABLATION
+    if (getenv("MOT_C16_1024_OLD")) return false;
+#endif
+    return true;
+}
 static C16Shape c16_shape(int Dm) {
     switch (Dm) {
-        case 256: return {2, 2, 3};
-        case 512: return {2, 4, 3};
-        case 768: return {2, 6, 3};
-        default: return {1, 8, 2};   // 1024: two stages of 64 KiB
+        case 256: return {2, 2, 3, 1};
+        case 512: return {2, 4, 3, 1};
+        case 768: return {2, 6, 3, 1};
+        default: return c16_two_pass() ? C16Shape{2, 4, 3, 2} : C16Shape{1, 8, 2, 1};   // 1024
     }
 }
 
@@ -529,7 +584,7 @@ bool concat16_usable(const MotEmbedMixDesc &d) {
     if (Dm != 256 && Dm != 512 && Dm != 768 && Dm != 1024) return false;
     if (((uintptr_t)d.weight | (uintptr_t)d.tok_table | (uintptr_t)d.byte_table | (uintptr_t)d.out) & 15) return false;
     const C16Shape sh = c16_shape(Dm);
-    return c16_lds_base(sh.MT, sh.NT, sh.NS, d.bpt) + (size_t)d.byte_rows * 4 <= 160 * 1024;
+    return c16_lds_base(sh.MT, sh.NT, sh.NS, d.bpt) + (size_t)d.byte_rows * 4 + (sh.NH > 1 ? 64 * sh.MT * 4 : 0) <= 160 * 1024;
 }
 
 // rn_byte: per-row rms factors of the byte table (launch_rows_rnorm); null when the byte part is not normalised or the table is
@@ -550,7 +605,7 @@ int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64
         case 256: return launch_c16<2, 2, 3>(P, stream);
         case 512: return launch_c16<2, 4, 3>(P, stream);
         case 768: return launch_c16<2, 6, 3>(P, stream);
-        default: return launch_c16<1, 8, 2>(P, stream);
+        default: return c16_two_pass() ? launch_c16<2, 4, 3, 2>(P, stream) : launch_c16<1, 8, 2>(P, stream);
     }
 }
 
