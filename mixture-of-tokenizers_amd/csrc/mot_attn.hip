@@ -30,6 +30,14 @@ namespace mot {
 
 constexpr int kHd = 128;  // head_dim of every CrossAttention the reference builds (train_gpt.py:459)
 
+// a value every lane of the wave computed alike, moved into scalar registers: loop counters, positions and row bases derived from
+// the wave's (token, head) then run on the scalar unit -- the attention kernels are bound by VALU issue (950 vector instructions
+// per (token, head) in the forward before this: counters SQ_INSTS_VALU / SQ_WAVE_CYCLES, profiles/r03_cross_attn_pmc.txt)
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int64_t uni64(int64_t v) {
+    return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v));
+}
+
 struct AttnArgs {
     const float *q;       // [T, HD] projected queries
     float *y;             // [T, HD]
@@ -61,11 +69,12 @@ __global__ __launch_bounds__(kThreads) void kv_finish_kernel(float *__restrict__
 }
 
 __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) {
+#pragma clang fp contract(fast)   // fused multiply-adds: the parity bars of this mixin are tolerances against float64, not bit patterns
     const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * kWaves + uni(threadIdx.x >> 6);
     if (w >= A.T * A.H) return;
-    const int64_t t = w / A.H;
-    const int h = (int)(w - t * A.H);
+    const int64_t t = uni64(w / A.H);
+    const int h = uni((int)(w - t * A.H));
     const int HD = A.H * kHd;
     // q: per-head rms norm, then RoPE at position t (lines 278-279)
     const float *qp = A.q + t * HD + h * kHd;
@@ -85,8 +94,8 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
     int hk0 = h;
     if (A.layout == 0) {
         const int64_t r0 = ((int64_t)h * A.T + t) * A.bpt;
-        pos0 = r0 / A.H;
-        hk0 = (int)(r0 - pos0 * A.H);
+        pos0 = uni64(r0 / A.H);
+        hk0 = uni((int)(r0 - pos0 * A.H));
     }
     auto advance = [&](int64_t &pos, int &hk) {
         if (A.layout == 0) { if (++hk == A.H) { hk = 0; ++pos; } } else ++pos;
@@ -110,16 +119,29 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
     // pass 1: scores, lane c keeps s_c; then the softmax over the bpt keys across lanes (one exp for all of them, line 287)
     float sc = -FLT_MAX;
     {
+        // Two keys per trip: their eight loads are in flight together and their two wave sums interleave (a DPP step has to wait two
+        // cycles for its operand -- alone, the chain is padded with s_nop on the scalar unit, which all four SIMDs of a CU share and
+        // which was as busy as the vector unit here: 740 scalar instructions per (token, head)).
         int64_t pos = pos0, pos_cs = -1; int hk = hk0;
         float ck = 0.f, sk = 0.f;
-        for (int c = 0; c < A.bpt; ++c) {
+        auto partial = [&](int c) {   // this lane's part of q . rope(k_c); moves (pos, hk) on to the next key
             const float *kp = A.kt + (int64_t)__builtin_amdgcn_readlane(rowv, c) * HD + hk * kHd;
             const float k0 = kp[lane], k1 = kp[64 + lane];
             if (pos != pos_cs) { ck = A.cos_k[pos * 64 + lane]; sk = A.sin_k[pos * 64 + lane]; pos_cs = pos; }   // as_viewed walks H heads per position
             const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
-            const float s = wave_sum(q0 * ka + q1 * kb) * inv_sqrt_hd;
-            if (lane == c) sc = s;
             advance(pos, hk);
+            return q0 * ka + q1 * kb;
+        };
+        int c = 0;
+        for (; c + 1 < A.bpt; c += 2) {
+            const float pa = partial(c), pb = partial(c + 1);
+            const float sa = wave_sum(pa) * inv_sqrt_hd, sb = wave_sum(pb) * inv_sqrt_hd;
+            if (lane == c) sc = sa;
+            if (lane == c + 1) sc = sb;
+        }
+        if (c < A.bpt) {
+            const float s = wave_sum(partial(c)) * inv_sqrt_hd;
+            if (lane == c) sc = s;
         }
     }
     const float mx = wave_max(sc);
@@ -130,12 +152,23 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
     {
         int hk = hk0;
         int64_t pos = pos0;
-        for (int c = 0; c < A.bpt; ++c) {
+        auto value = [&](int c, float &v0, float &v1) {
             const float *vp = A.vt + (int64_t)__builtin_amdgcn_readlane(rowv, c) * HD + hk * kHd;
-            const float pc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), c));
-            y0 += pc * vp[lane];
-            y1 += pc * vp[64 + lane];
+            v0 = vp[lane]; v1 = vp[64 + lane];
             advance(pos, hk);
+            return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p), c));
+        };
+        int c = 0;
+        for (; c + 1 < A.bpt; c += 2) {   // (two keys per trip, as above; the sums keep their order)
+            float a0, a1, b0, b1;
+            const float pa = value(c, a0, a1), pb = value(c + 1, b0, b1);
+            y0 += pa * a0; y1 += pa * a1;
+            y0 += pb * b0; y1 += pb * b1;
+        }
+        if (c < A.bpt) {
+            float a0, a1;
+            const float pa = value(c, a0, a1);
+            y0 += pa * a0; y1 += pa * a1;
         }
     }
     float *yp = A.y + t * HD + h * kHd;
@@ -299,11 +332,12 @@ struct AttnBwdArgs {
 };
 
 __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdArgs A) {
+#pragma clang fp contract(fast)
     const int lane = threadIdx.x & 63;
-    const int64_t w = (int64_t)blockIdx.x * kWaves + (threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * kWaves + uni(threadIdx.x >> 6);
     if (w >= A.T * A.H) return;
-    const int64_t t = w / A.H;
-    const int h = (int)(w - t * A.H);
+    const int64_t t = uni64(w / A.H);
+    const int h = uni((int)(w - t * A.H));
     const int HD = A.H * kHd;
     const float lam = *A.lambda;
     const float inv_sqrt = 1.0f / sqrtf((float)kHd);
@@ -319,8 +353,8 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     int hk0 = h;
     if (A.layout == 0) {
         const int64_t r0 = ((int64_t)h * A.T + t) * A.bpt;
-        pos0 = r0 / A.H;
-        hk0 = (int)(r0 - pos0 * A.H);
+        pos0 = uni64(r0 / A.H);
+        hk0 = uni((int)(r0 - pos0 * A.H));
     }
     auto advance = [&](int64_t &pos, int &hk) {
         if (A.layout == 0) { if (++hk == A.H) { hk = 0; ++pos; } } else ++pos;
@@ -343,14 +377,24 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     {
         int64_t pos = pos0, pos_cs = -1; int hk = hk0;
         float ck = 0.f, sk = 0.f;
-        for (int c = 0; c < A.bpt; ++c) {
+        auto partial = [&](int c) {   // two keys per trip in every pass, as in the forward kernel
             const float *kp = A.kn + row_at(c) * HD + hk * kHd;
             const float k0 = kp[lane], k1 = kp[64 + lane];
             if (pos != pos_cs) { ck = A.cos_k[pos * 64 + lane]; sk = A.sin_k[pos * 64 + lane]; pos_cs = pos; }
             const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
-            const float s = wave_sum(q0 * ka + q1 * kb) * inv_sqrt;
-            if (lane == c) sc = s;
             advance(pos, hk);
+            return q0 * ka + q1 * kb;
+        };
+        int c = 0;
+        for (; c + 1 < A.bpt; c += 2) {
+            const float pa = partial(c), pb = partial(c + 1);
+            const float sa = wave_sum(pa) * inv_sqrt, sb = wave_sum(pb) * inv_sqrt;
+            if (lane == c) sc = sa;
+            if (lane == c + 1) sc = sb;
+        }
+        if (c < A.bpt) {
+            const float s = wave_sum(partial(c)) * inv_sqrt;
+            if (lane == c) sc = s;
         }
     }
     const float mx = wave_max(sc);
@@ -360,12 +404,22 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     float dp = 0.f;
     {
         int64_t pos = pos0; int hk = hk0;
-        for (int c = 0; c < A.bpt; ++c) {
+        auto partial = [&](int c) {
             const float *vp = A.vpre + row_at(c) * HD + hk * kHd;
             const float v0 = lam * vp[lane], v1 = lam * vp[64 + lane];
-            const float d = wave_sum(dy0 * v0 + dy1 * v1);
-            if (lane == c) dp = d;
             advance(pos, hk);
+            return dy0 * v0 + dy1 * v1;
+        };
+        int c = 0;
+        for (; c + 1 < A.bpt; c += 2) {
+            const float pa = partial(c), pb = partial(c + 1);
+            const float da = wave_sum(pa), db = wave_sum(pb);
+            if (lane == c) dp = da;
+            if (lane == c + 1) dp = db;
+        }
+        if (c < A.bpt) {
+            const float d = wave_sum(partial(c));
+            if (lane == c) dp = d;
         }
     }
     const float dot = wave_sum(p * dp);
@@ -382,15 +436,25 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     {
         int64_t pos = pos0, pos_cs = -1; int hk = hk0;
         float ck = 0.f, sk = 0.f;
-        for (int c = 0; c < A.bpt; ++c) {
+        auto rotated = [&](int c, float &ka, float &kb) {
             const float *kp = A.kn + row_at(c) * HD + hk * kHd;
             const float k0 = kp[lane], k1 = kp[64 + lane];
             if (pos != pos_cs) { ck = A.cos_k[pos * 64 + lane]; sk = A.sin_k[pos * 64 + lane]; pos_cs = pos; }
-            const float ka = k0 * ck + k1 * sk, kb = k0 * (-sk) + k1 * ck;
-            const float dsc = __shfl(ds, c, 64);
-            dq0 += dsc * ka;
-            dq1 += dsc * kb;
+            ka = k0 * ck + k1 * sk; kb = k0 * (-sk) + k1 * ck;
             advance(pos, hk);
+            return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ds), c));
+        };
+        int c = 0;
+        for (; c + 1 < A.bpt; c += 2) {
+            float a0, a1, b0, b1;
+            const float da = rotated(c, a0, a1), db = rotated(c + 1, b0, b1);
+            dq0 += da * a0; dq1 += da * a1;
+            dq0 += db * b0; dq1 += db * b1;
+        }
+        if (c < A.bpt) {
+            float a0, a1;
+            const float da = rotated(c, a0, a1);
+            dq0 += da * a0; dq1 += da * a1;
         }
     }
     // q: rope^T, head-norm^T
