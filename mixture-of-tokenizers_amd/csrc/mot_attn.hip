@@ -181,6 +181,156 @@ __global__ __launch_bounds__(kThreads) void cross_attn_kernel(const AttnArgs A) 
 }
 
 
+// The same attention for bpt <= 16, a lane per (key, quarter of the head) instead of a loop over the keys: lane 4c + j holds the
+// dims 16i + 4j .. + 3 (i = 0..7) of key c -- every 16-byte load of a wave-instruction takes 64 contiguous bytes of each of 16 rows
+// -- rotates them with its own position's cos / sin and multiplies with the query, which the wave normalises and rotates once in
+// the one-lane-per-dim form and passes through 512 bytes of LDS.  A score is then a sum over 32 products in a lane and two quad
+// permutes (the loop: 2 products and a 6-step wave sum PER KEY, 950 vector and 400 scalar instructions per (token, head); this
+// form about 300 and 60).  The values are summed a lane per (key parity, 4 dims): 8 row-wide loads, weights by v_readlane.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += dpp_move<kDppQuadXor1, 0xf>(0.f, v);
+    v += dpp_move<kDppQuadXor2, 0xf>(0.f, v);
+    return v;
+}
+constexpr int kQuadPos = 4;         // positions whose cos / sin rows a wave stages in LDS
+constexpr int kQuadPosStride = 80;  // floats between them: 64 + 16, so that the quads of keys on different positions read different banks
+__device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__global__ __launch_bounds__(kThreads) void cross_attn_quad_kernel(const AttnArgs A) {
+#pragma clang fp contract(fast)
+    __shared__ __attribute__((aligned(16))) float qs[kWaves][kHd];
+    __shared__ __attribute__((aligned(16))) float cs[kWaves][2][kQuadPos * kQuadPosStride];
+    const int lane = threadIdx.x & 63, wv = uni(threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * kWaves + wv;
+    if (w >= A.T * A.H) return;
+    // which (token, head): head-major for the viewed layout -- the keys of (h, t) are the flat rows (h T + t) bpt + c, so waves that
+    // follow each other share positions (cos / sin rows) and, all being on one head, gather from one 128-wide slice of the two
+    // tables (458 x 512 bytes each, a few dozen rows of it hot: L1-sized); token-major for the per-head layout, whose H heads of a
+    // token share their bpt positions
+    int64_t t; int h;
+    if (A.layout == 0) { h = uni((int)(w / A.T)); t = w - (int64_t)h * A.T; }
+    else { t = uni64(w / A.H); h = uni((int)(w - t * A.H)); }
+    const int HD = A.H * kHd;
+    {   // q: per-head rms norm, then RoPE at position t (lines 278-279), one lane per pair of dims
+        const float *qp = A.q + t * HD + h * kHd;
+        float q0 = qp[lane], q1 = qp[64 + lane];
+        const float rq = rms_scale(wave_sum(q0 * q0 + q1 * q1), kHd, A.eps);
+        q0 *= rq;
+        q1 *= rq;
+        const float c = A.cos_q[t * 64 + lane], s = A.sin_q[t * 64 + lane];
+        qs[wv][lane] = q0 * c + q1 * s;
+        qs[wv][64 + lane] = q0 * (-s) + q1 * c;
+    }
+    // this lane's key: flat row r of the (T*bpt, H, hd) key / value memory = pos * H + hk
+    const int c = lane >> 2, j = lane & 3;
+    const bool live = c < A.bpt;
+    const int ce = live ? c : A.bpt - 1;   // lanes past the last key repeat it (valid addresses) with weight 0
+    int64_t pos = t * A.bpt + ce;
+    int hk = h, dpos = 0;
+    bool staged = false;
+    if (A.layout == 0) {
+        const int64_t r0 = ((int64_t)h * A.T + t) * A.bpt;
+        const int64_t pos0 = uni64(r0 / A.H);
+        const int hk0 = uni((int)(r0 - pos0 * A.H)), hc = hk0 + ce;
+        dpos = hc / A.H;
+        pos = pos0 + dpos;
+        hk = hc - dpos * A.H;
+        // the bpt keys sit on (hk0 + bpt - 1) / H + 1 positions (4 of them for 16 keys of 6 heads): their cos / sin rows are loaded once,
+        // a lane per pair of dims, and handed to the lanes of their keys through LDS -- the texture addresser, 64 bytes a cycle, is what
+        // this kernel keeps busy (TA_BUSY 85 % with every lane loading the 128 bytes of its own key's rows)
+        const int np = (hk0 + A.bpt - 1) / A.H + 1;
+        staged = np <= kQuadPos;
+        if (staged) {
+            for (int n = 0; n < np; ++n) {
+                cs[wv][0][n * kQuadPosStride + lane] = A.cos_k[(pos0 + n) * 64 + lane];
+                cs[wv][1][n * kQuadPosStride + lane] = A.sin_k[(pos0 + n) * 64 + lane];
+            }
+        }
+    }
+    int64_t row = pos;
+    if (A.ids) {
+        row = A.ids[pos];
+        if ((uint64_t)row >= (uint64_t)A.rows) {
+            if (A.status) atomicOr(A.status, kStatusByteOor);
+            row = 0;
+        }
+    }
+    const int off4 = (int)((row * HD + hk * kHd) >> 2);   // this key's head slice, in 16-byte units (the host checks rows * HD < 2^33)
+    const float4 *kp = (const float4 *)A.kt + off4 + j;
+    float4 k[8], ck[4], sk[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = kp[4 * i];
+    __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order: the rotated query and the cos / sin rows are there)
+    if (staged) {
+        const float *cp = &cs[wv][0][dpos * kQuadPosStride + 4 * j], *sp = &cs[wv][1][dpos * kQuadPosStride + 4 * j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ck[i] = *(const float4 *)(cp + 16 * i); sk[i] = *(const float4 *)(sp + 16 * i); }
+    } else {
+        const float4 *cp = (const float4 *)(A.cos_k + pos * 64) + j, *sp = (const float4 *)(A.sin_k + pos * 64) + j;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ck[i] = cp[4 * i]; sk[i] = sp[4 * i]; }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 qa = *(const float4 *)&qs[wv][16 * i + 4 * j], qb = *(const float4 *)&qs[wv][64 + 16 * i + 4 * j];
+        const float4 a = k[i], b = k[i + 4], cc = ck[i], ss = sk[i];
+        s += qa.x * (a.x * cc.x + b.x * ss.x) + qb.x * (b.x * cc.x - a.x * ss.x);
+        s += qa.y * (a.y * cc.y + b.y * ss.y) + qb.y * (b.y * cc.y - a.y * ss.y);
+        s += qa.z * (a.z * cc.z + b.z * ss.z) + qb.z * (b.z * cc.z - a.z * ss.z);
+        s += qa.w * (a.w * cc.w + b.w * ss.w) + qb.w * (b.w * cc.w - a.w * ss.w);
+    }
+    const float inv_sqrt_hd = 1.0f / sqrtf((float)kHd);
+    const float sc = live ? quad_sum(s) * inv_sqrt_hd : -FLT_MAX;
+    const float mx = wave_max(sc);
+    float p = live ? expf(sc - mx) : 0.f;
+    p /= wave_sum(j == 0 ? p : 0.f);
+    // y = sum_c p_c v_c: lanes 0..31 take the even keys, 32..63 the odd ones, 4 dims each
+    const int g = lane >> 5, m = lane & 31;
+    const float4 *vt4 = (const float4 *)A.vt + m;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto two_keys = [&](int cc) {
+        const int l0 = 8 * cc, l1 = 8 * cc + 4;
+        const int o0 = __builtin_amdgcn_readlane(off4, l0), o1 = __builtin_amdgcn_readlane(off4, l1);
+        const float p0 = lane_value(p, l0), p1 = lane_value(p, l1);
+        const float4 v = vt4[g ? o1 : o0];
+        const float pc = g ? p1 : p0;
+        y.x += pc * v.x; y.y += pc * v.y; y.z += pc * v.z; y.w += pc * v.w;
+    };
+    if (A.bpt > 14) {
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) two_keys(cc);
+    } else {
+        for (int cc = 0; 2 * cc < A.bpt; ++cc) two_keys(cc);
+    }
+    y.x += __shfl_xor(y.x, 32, 64); y.y += __shfl_xor(y.y, 32, 64); y.z += __shfl_xor(y.z, 32, 64); y.w += __shfl_xor(y.w, 32, 64);
+    const int64_t o = t * HD + h * kHd + 4 * m;
+    if (g == 0) *(float4 *)(A.y + o) = y;
+    else if (A.y16) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 b; b[0] = (__bf16)y.x; b[1] = (__bf16)y.y; b[2] = (__bf16)y.z; b[3] = (__bf16)y.w;
+        *(bf16x4 *)(A.y16 + o) = b;
+    }
+}
+
+
+// the lane-per-(key, quarter) kernels: at most 16 keys, 16-byte loads of rows they address in 16-byte units with 32 bits
+static bool quad_form(int bpt, int64_t rows, int HD, const void *k, const void *v, const void *cos_k, const void *sin_k) {
+    bool ok = bpt <= 16 && (uint64_t)rows * HD < ((uint64_t)1 << 33) && !(((uintptr_t)k | (uintptr_t)v | (uintptr_t)cos_k | (uintptr_t)sin_k) & 15);
+#ifdef MOT_DEV_ABLATION
+    if (getenv("MOT_ATTN_LOOP")) ok = false;
+#endif
+    return ok;
+}
+static int launch_attention(const AttnArgs &A, hipStream_t stream) {
+    const int64_t waves = A.T * A.H;
+    const dim3 grid((unsigned)((waves + kWaves - 1) / kWaves));
+    if (quad_form(A.bpt, A.rows, A.H * kHd, A.kt, A.vt, A.cos_k, A.sin_k) && !(((uintptr_t)A.y | (uintptr_t)A.y16) & 15))
+        hipLaunchKernelGGL(cross_attn_quad_kernel, grid, dim3(kThreads), 0, stream, A);
+    else hipLaunchKernelGGL(cross_attn_kernel, grid, dim3(kThreads), 0, stream, A);
+    return check_launch("cross_attn_kernel");
+}
+
 // ------------------------------------------------------------------------------------------ host
 // workspace, in floats: [q: T*HD][y: T*HD][kt: R*HD][vt: R*HD][xkv: R*D (dual: R = T*bpt)][xq: D > HD ? T*D : 0]
 struct AttnLayout { size_t q, y, kt, vt, xkv, xq, a16, w16, total; int64_t R; };
@@ -287,9 +437,7 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     A.q = q; A.y = y; A.kt = kt; A.vt = vt; A.ids = dual ? nullptr : d.ids_a; A.rows = L.R; A.T = T; A.bpt = d.bpt; A.H = H;
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
     A.y16 = mm16(d) ? (__bf16 *)(ws + L.a16) : nullptr;   // (the row operand of q has been consumed: stream order)
-    const int64_t waves = T * H;
-    hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
-    if ((rc = check_launch("cross_attn_kernel"))) return rc;
+    if ((rc = launch_attention(A, stream))) return rc;
     // 4. out = c_proj y                   (line 293): out[t][c] = sum_r y[t][r] * proj_w[c][r]
     if (mm16(d)) {
         if ((rc = launch_narrow((const float *)d.proj_w, (int64_t)D * HD, ws + L.w16, stream))) return rc;
@@ -468,6 +616,129 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
     float *o = A.dq + t * HD + h * kHd;
     o[lane] = rq * (dn0 - qn0 * m);
     o[64 + lane] = rq * (dn1 - qn1 * m);
+}
+
+// The same for bpt <= 16 in the forward's lane-per-(key, quarter) form (cross_attn_quad_kernel): the keys are loaded and rotated
+// once and stay in registers for the query gradient, whose sum over the keys runs over the lanes of a 16-lane row by two DPP
+// rotates and over the four rows through 2 KB of LDS.
+__global__ __launch_bounds__(kThreads) void cross_attn_bwd_quad_kernel(const AttnBwdArgs A) {
+#pragma clang fp contract(fast)
+    __shared__ __attribute__((aligned(16))) float qs[kWaves][kHd], dys[kWaves][kHd], red[kWaves][4][kHd];
+    __shared__ __attribute__((aligned(16))) float cs[kWaves][2][kQuadPos * kQuadPosStride];
+    const int lane = threadIdx.x & 63, wv = uni(threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * kWaves + wv;
+    if (w >= A.T * A.H) return;
+    int64_t t; int h;   // (head-major for the viewed layout, as in the forward)
+    if (A.layout == 0) { h = uni((int)(w / A.T)); t = w - (int64_t)h * A.T; }
+    else { t = uni64(w / A.H); h = uni((int)(w - t * A.H)); }
+    const int HD = A.H * kHd;
+    const int64_t th = t * A.H + h, o128 = t * HD + h * kHd;
+    const float lam = *A.lambda;
+    const float inv_sqrt = 1.0f / sqrtf((float)kHd);
+    // q: head norm + RoPE, a lane per pair of dims; kept for the way back
+    const float qp0 = A.q_pre[o128 + lane], qp1 = A.q_pre[o128 + 64 + lane];
+    const float rq = rms_scale(wave_sum(qp0 * qp0 + qp1 * qp1), kHd, A.eps);
+    const float qn0 = qp0 * rq, qn1 = qp1 * rq;
+    const float cq = A.cos_q[t * 64 + lane], sq = A.sin_q[t * 64 + lane];
+    {
+        const float q0 = qn0 * cq + qn1 * sq, q1 = qn0 * (-sq) + qn1 * cq;
+        qs[wv][lane] = q0; qs[wv][64 + lane] = q1;
+        A.qrot[o128 + lane] = q0; A.qrot[o128 + 64 + lane] = q1;   // (the per-table-row sums need it)
+        dys[wv][lane] = A.dy[o128 + lane]; dys[wv][64 + lane] = A.dy[o128 + 64 + lane];
+    }
+    const int c = lane >> 2, j = lane & 3;
+    const bool live = c < A.bpt;
+    const int ce = live ? c : A.bpt - 1;
+    int64_t pos = t * A.bpt + ce;
+    int hk = h, dpos = 0;
+    bool staged = false;
+    if (A.layout == 0) {
+        const int64_t r0 = ((int64_t)h * A.T + t) * A.bpt;
+        const int64_t pos0 = uni64(r0 / A.H);
+        const int hk0 = uni((int)(r0 - pos0 * A.H)), hc = hk0 + ce;
+        dpos = hc / A.H;
+        pos = pos0 + dpos;
+        hk = hc - dpos * A.H;
+        const int np = (hk0 + A.bpt - 1) / A.H + 1;
+        staged = np <= kQuadPos;
+        if (staged) {
+            for (int n = 0; n < np; ++n) {
+                cs[wv][0][n * kQuadPosStride + lane] = A.cos_k[(pos0 + n) * 64 + lane];
+                cs[wv][1][n * kQuadPosStride + lane] = A.sin_k[(pos0 + n) * 64 + lane];
+            }
+        }
+    }
+    int64_t row = pos;   // two id tensors: the key / value rows are per kv position
+    if (A.ids) {
+        row = A.ids[pos];
+        if ((uint64_t)row >= (uint64_t)A.rows) row = 0;   // flagged by the forward
+    }
+    const int off4 = (int)((row * HD + hk * kHd) >> 2);
+    const float4 *kp = (const float4 *)A.kn + off4 + j, *vp = (const float4 *)A.vpre + off4 + j;
+    float4 k[8], v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] = kp[4 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = vp[4 * i];
+    __builtin_amdgcn_wave_barrier();
+    const float *cl = &cs[wv][0][dpos * kQuadPosStride + 4 * j], *sl = &cs[wv][1][dpos * kQuadPosStride + 4 * j];
+    const float4 *cg = (const float4 *)(A.cos_k + pos * 64) + j, *sg = (const float4 *)(A.sin_k + pos * 64) + j;
+    // scores (the keys rotated in place) and dp_c = dy . v_c
+    float s = 0.f, dpv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 qa = *(const float4 *)&qs[wv][16 * i + 4 * j], qb = *(const float4 *)&qs[wv][64 + 16 * i + 4 * j];
+        const float4 da = *(const float4 *)&dys[wv][16 * i + 4 * j], db = *(const float4 *)&dys[wv][64 + 16 * i + 4 * j];
+        const float4 a = k[i], b = k[i + 4];
+        const float4 cc = staged ? *(const float4 *)(cl + 16 * i) : cg[4 * i], ss = staged ? *(const float4 *)(sl + 16 * i) : sg[4 * i];
+        k[i].x = a.x * cc.x + b.x * ss.x; k[i + 4].x = b.x * cc.x - a.x * ss.x;
+        k[i].y = a.y * cc.y + b.y * ss.y; k[i + 4].y = b.y * cc.y - a.y * ss.y;
+        k[i].z = a.z * cc.z + b.z * ss.z; k[i + 4].z = b.z * cc.z - a.z * ss.z;
+        k[i].w = a.w * cc.w + b.w * ss.w; k[i + 4].w = b.w * cc.w - a.w * ss.w;
+        s += qa.x * k[i].x + qb.x * k[i + 4].x;
+        s += qa.y * k[i].y + qb.y * k[i + 4].y;
+        s += qa.z * k[i].z + qb.z * k[i + 4].z;
+        s += qa.w * k[i].w + qb.w * k[i + 4].w;
+        dpv += da.x * v[i].x + db.x * v[i + 4].x;
+        dpv += da.y * v[i].y + db.y * v[i + 4].y;
+        dpv += da.z * v[i].z + db.z * v[i + 4].z;
+        dpv += da.w * v[i].w + db.w * v[i + 4].w;
+
+    }
+    const float sc = live ? quad_sum(s) * inv_sqrt : -FLT_MAX;
+    const float mx = wave_max(sc);
+    float p = live ? expf(sc - mx) : 0.f;
+    p /= wave_sum(j == 0 ? p : 0.f);
+    const float dp = lam * quad_sum(dpv);
+    const float dot = wave_sum(j == 0 ? p * dp : 0.f);
+    const float ds = p * (dp - dot) * inv_sqrt;
+    if (live && j == 0) {
+        A.pw[th * A.bpt + c] = p;
+        A.dsw[th * A.bpt + c] = ds;
+    }
+    // dq_r = sum_c ds_c k_r: over the four keys of a 16-lane row by DPP, over the four rows through LDS
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float4 x = make_float4(ds * k[i].x, ds * k[i].y, ds * k[i].z, ds * k[i].w);
+        x.x += dpp_move<kDppRowRor4, 0xf>(0.f, x.x); x.y += dpp_move<kDppRowRor4, 0xf>(0.f, x.y);
+        x.z += dpp_move<kDppRowRor4, 0xf>(0.f, x.z); x.w += dpp_move<kDppRowRor4, 0xf>(0.f, x.w);
+        x.x += dpp_move<kDppRowRor8, 0xf>(0.f, x.x); x.y += dpp_move<kDppRowRor8, 0xf>(0.f, x.y);
+        x.z += dpp_move<kDppRowRor8, 0xf>(0.f, x.z); x.w += dpp_move<kDppRowRor8, 0xf>(0.f, x.w);
+        if ((lane & 12) == 0) *(float4 *)&red[wv][lane >> 4][16 * i + 4 * j] = x;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float dq0 = (red[wv][0][lane] + red[wv][1][lane]) + (red[wv][2][lane] + red[wv][3][lane]);
+    const float dq1 = (red[wv][0][64 + lane] + red[wv][1][64 + lane]) + (red[wv][2][64 + lane] + red[wv][3][64 + lane]);
+    // q: rope^T, head-norm^T
+    const float dn0 = dq0 * cq - dq1 * sq, dn1 = dq0 * sq + dq1 * cq;
+    const float m = wave_sum(dn0 * qn0 + dn1 * qn1) / (float)kHd;
+    if (A.dq16) {
+        A.dq16[o128 + lane] = (__bf16)(rq * (dn0 - qn0 * m));
+        A.dq16[o128 + 64 + lane] = (__bf16)(rq * (dn1 - qn1 * m));
+        return;
+    }
+    A.dq[o128 + lane] = rq * (dn0 - qn0 * m);
+    A.dq[o128 + 64 + lane] = rq * (dn1 - qn1 * m);
 }
 
 // Gradients of the per-row key / value tables: dkn_tab[r] = sum over the kv positions with byte id r of rope^T(ds * q_rot),
@@ -805,10 +1076,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
     A.y16 = nullptr;
     const int64_t waves = T * H;
-    if (!d.saved_qy) {
-        hipLaunchKernelGGL(cross_attn_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, A);
-        if ((rc = check_launch("cross_attn_kernel"))) return rc;
-    }
+    if (!d.saved_qy && (rc = launch_attention(A, stream))) return rc;
     // ---- c_proj:  dW_p += g^T y;  dy = g W_p   (proj_w [D, HD] is the k-major operand of g[T, D] -> dy[T, HD])
     // (matmul_dtype == MOT_BF16: the four products over the tokens -- dW_p, dy, dW_q, dxq -- on the bf16 MFMA, row operands rounded
     //  to bf16 as the reference's bf16 autograd has them, fp32 sums; b0 = g, then xq; b1 = y, then dq; w16 = the k-major weight)
@@ -831,7 +1099,9 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     B.layout = d.head_layout; B.cos_q = d.cos_q; B.sin_q = d.sin_q; B.cos_k = d.cos_k; B.sin_k = d.sin_k; B.eps = eps;
     B.dq = dq; B.pw = pw; B.dsw = dsw; B.qrot = qrot;
     B.dq16 = mm16(d) ? (__bf16 *)(ws + L.dq16) : nullptr;
-    hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
+    if (quad_form(B.bpt, R, HD, B.kn, B.vpre, B.cos_k, B.sin_k))
+        hipLaunchKernelGGL(cross_attn_bwd_quad_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
+    else hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
     if ((rc = check_launch("cross_attn_bwd_kernel"))) return rc;
     // ---- per byte-table row: the sums over the kv positions of every byte id, from the grouped positions
     {
