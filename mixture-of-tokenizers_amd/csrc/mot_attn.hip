@@ -826,6 +826,19 @@ __global__ __launch_bounds__(kThreads) void attn_kv_rows_bwd_h_kernel(const Attn
         const int cnt = (int)min((int64_t)64, s_end - s0);
         int vpos = 0, vid = 0;
         if (lane < cnt) { vpos = A.pos_sorted[s0 + lane]; vid = A.id_sorted[s0 + lane]; }
+        // owner (query token, head, key index) of slot (pos, 0), a lane per position: the two 64-bit divisions are vector work once
+        // per 64 positions (on the scalar unit, once per position, they made this kernel scalar-bound: 230 scalar instructions per
+        // position, the CU's one scalar unit 80 % busy)
+        int vtq, vhq = 0, vc;
+        if (A.layout == 0) {
+            const int64_t r = (int64_t)vpos * HH, qi = r / A.bpt;
+            vc = (int)(r - qi * A.bpt);
+            vhq = (int)(qi / A.T);
+            vtq = (int)(qi - (int64_t)vhq * A.T);
+        } else {
+            vtq = vpos / A.bpt;
+            vc = vpos - vtq * A.bpt;
+        }
         for (int k = 0; k < cnt; ++k) {
             const int64_t pos = __builtin_amdgcn_readlane(vpos, k);
             const int id = __builtin_amdgcn_readlane(vid, k);
@@ -836,14 +849,37 @@ __global__ __launch_bounds__(kThreads) void attn_kv_rows_bwd_h_kernel(const Attn
                 for (int hk = 0; hk < HH; ++hk) dv0[hk] = dv1[hk] = dk0[hk] = dk1[hk] = 0.f;
             }
             const float ck = A.cos_k[pos * 64 + lane], sk = A.sin_k[pos * 64 + lane];
-            // owner of slot (pos, 0); the following slots advance the key index c, then the query index qi
-            int64_t qi, tq; int c, hq;
-            if (A.layout == 0) {
-                const int64_t r = pos * HH;
-                qi = r / A.bpt; c = (int)(r - qi * A.bpt);
-                hq = (int)(qi / A.T); tq = qi - (int64_t)hq * A.T;
-            } else {
-                tq = pos / A.bpt; c = (int)(pos - tq * A.bpt); hq = 0; qi = 0;
+            // the following slots advance the key index c, then the query index
+            int64_t tq = __builtin_amdgcn_readlane(vtq, k);
+            int c = __builtin_amdgcn_readlane(vc, k), hq = __builtin_amdgcn_readlane(vhq, k);
+            if (A.layout == 0 && A.bpt >= HH) {
+                // the HH slots of a position are keys c .. c + HH - 1 of ONE query, or run on into the next query's first keys: its
+                // dy and rotated-query slices are loaded once (twice), not once per slot (26 wave-loads per position -> 6 or 10)
+                const int64_t rowa = tq * HD + hq * kHd, sa = (tq * HH + hq) * A.bpt + c;
+                const float ya0 = A.dy[rowa + lane], ya1 = A.dy[rowa + 64 + lane], xa0 = A.qrot[rowa + lane], xa1 = A.qrot[rowa + 64 + lane];
+                float yb0 = 0.f, yb1 = 0.f, xb0 = 0.f, xb1 = 0.f;
+                int64_t sb = 0;
+                const int na = min(HH, A.bpt - c);   // slots of the first query
+                if (na < HH) {   // the next query of the (H, T) grid
+                    int64_t tb = tq + 1; int hb = hq;
+                    if (tb == A.T) { tb = 0; ++hb; }
+                    const int64_t rowb = tb * HD + hb * kHd;
+                    sb = (tb * HH + hb) * A.bpt - na;
+                    yb0 = A.dy[rowb + lane]; yb1 = A.dy[rowb + 64 + lane]; xb0 = A.qrot[rowb + lane]; xb1 = A.qrot[rowb + 64 + lane];
+                }
+#pragma unroll
+                for (int hk = 0; hk < HH; ++hk) {
+                    const bool first = hk < na;
+                    const int64_t sidx = (first ? sa : sb) + hk;
+                    const float p = A.pw[sidx], ds = A.dsw[sidx];
+                    const float y0 = first ? ya0 : yb0, y1 = first ? ya1 : yb1, x0 = first ? xa0 : xb0, x1 = first ? xa1 : xb1;
+                    dv0[hk] += p * y0;
+                    dv1[hk] += p * y1;
+                    const float g0 = ds * x0, g1 = ds * x1;
+                    dk0[hk] += g0 * ck - g1 * sk;
+                    dk1[hk] += g0 * sk + g1 * ck;
+                }
+                continue;
             }
 #pragma unroll
             for (int hk = 0; hk < HH; ++hk) {
