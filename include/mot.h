@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MOT_ABI_VERSION 11
+#define MOT_ABI_VERSION 12
 #define MOT_MAX_BPT 64 /* bytes (characters) per token; the reference uses 3, 8, 16, 18, 20, 32 */
 
 typedef void *mot_stream_t; /* hipStream_t */
@@ -340,7 +340,11 @@ typedef struct MotCrossAttnDesc {
      * `self.q_w.type_as(x)`, train_gpt.py:185-186, 277-278; x bf16 since 1124-1126); tables, attention and every result stay
      * fp32.  Needs dim % 8 == 0.  Workspace sizes depend on it. */
     int32_t matmul_dtype;
-    int32_t reserved0;
+    /* MOT_F32 (0) or, with matmul_dtype == MOT_BF16, MOT_BF16: the element type of `out` (forward) and of MotCrossAttnGrads.grad_out
+     * (backward).  bf16 is what the reference's module returns and receives in the production cast; the last product then writes
+     * bf16 itself (one rounding of the fp32 sums, as a caller's cast of the fp32 result would do) and the backward's bf16 products
+     * take grad_out as it is -- a widening and a narrowing pass over [T, dim] less on each side of the boundary. */
+    int32_t io_dtype;
     /* optional, with matmul_dtype == MOT_BF16: the caller's bf16 token table [tok_rows, dim] whose widened copy `tok_table` is.
      * The normalised token rows -- the row operand of W_q and of dW_q -- are then gathered in bf16 directly (the same values: norm
      * in fp32, one rounding), without the fp32 detour. */

@@ -31,7 +31,7 @@ MIX_NOOP, MIX_SUM, MIX_MEAN, MIX_CONCAT_LINEAR = 0, 1, 2, 3
 IDS_NONE, IDS_FROM_TTB, IDS_GIVEN = 0, 1, 2
 F32, BF16 = 0, 1
 MAX_BPT = 64
-ABI_VERSION = 11
+ABI_VERSION = 12
 FLAG_LINEAR_ONE_LAUNCH, FLAG_MEAN_GENERIC, FLAG_BWD_DU_FP32, FLAG_LINEAR_COMPOSED = 1, 2, 4, 8
 HEADS_AS_VIEWED, HEADS_PER_TOKEN = 0, 1
 
@@ -95,7 +95,7 @@ class MotCrossAttnDesc(C.Structure):
         ("cos_q", C.c_void_p), ("sin_q", C.c_void_p), ("cos_k", C.c_void_p), ("sin_k", C.c_void_p),
         ("rot_q_len", C.c_int64), ("rot_k_len", C.c_int64), ("eps", C.c_float), ("kv_tables_ready", C.c_int32),
         ("out", C.c_void_p), ("status", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-        ("kv_tables", C.c_void_p), ("saved_qy", C.c_void_p), ("matmul_dtype", C.c_int32), ("reserved0", C.c_int32),
+        ("kv_tables", C.c_void_p), ("saved_qy", C.c_void_p), ("matmul_dtype", C.c_int32), ("io_dtype", C.c_int32),
         ("tok_table_bf16", C.c_void_p),
     ]
 

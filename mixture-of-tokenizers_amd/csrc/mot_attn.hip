@@ -441,7 +441,7 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     // 4. out = c_proj y                   (line 293): out[t][c] = sum_r y[t][r] * proj_w[c][r]
     if (mm16(d)) {
         if ((rc = launch_narrow((const float *)d.proj_w, (int64_t)D * HD, ws + L.w16, stream))) return rc;
-        return launch_gemm_rows_bf16(ws + L.a16, HD, T, ws + L.w16, HD, HD, D, d.out, D, false, nullptr, stream);
+        return launch_gemm_rows_bf16(ws + L.a16, HD, T, ws + L.w16, HD, HD, D, d.out, D, d.io_dtype == MOT_BF16, nullptr, stream);
     }
     return launch_gemm_rows(y, (int)HD, T, (const float *)d.proj_w, (int)HD, (int)HD, (int)D, (float *)d.out, (int)D, true, stream);
 }
@@ -1118,13 +1118,15 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     //  to bf16 as the reference's bf16 autograd has them, fp32 sums; b0 = g, then xq; b1 = y, then dq; w16 = the k-major weight)
     __bf16 *b0 = (__bf16 *)(ws + L.b0), *b1 = (__bf16 *)(ws + L.b1), *w16 = (__bf16 *)(ws + L.w16);
     if (mm16(d)) {
-        if ((rc = launch_narrow(g_out, T * D, b0, stream))) return rc;
+        const __bf16 *g16 = b0;
+        if (d.io_dtype == MOT_BF16) g16 = (const __bf16 *)gr.grad_out;   // the caller's bf16 gradient as it is
+        else if ((rc = launch_narrow(g_out, T * D, b0, stream))) return rc;
         if (gr.d_proj_w) {
             if ((rc = launch_narrow(y, T * HD, b1, stream))) return rc;
-            if ((rc = launch_gemm_tn_bf16(b0, D, D, b1, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
+            if ((rc = launch_gemm_tn_bf16(g16, D, D, b1, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
         }
         if ((rc = launch_narrow_transpose((const float *)d.proj_w, D, HD, w16, stream))) return rc;   // [HD][D]
-        if ((rc = launch_gemm_rows_bf16(b0, D, T, w16, D, D, HD, dy, HD, false, nullptr, stream))) return rc;
+        if ((rc = launch_gemm_rows_bf16(g16, D, T, w16, D, D, HD, dy, HD, false, nullptr, stream))) return rc;
     } else {
         if (gr.d_proj_w && (rc = launch_gemm_tn(g_out, D, D, y, HD, HD, T, (float *)gr.d_proj_w, HD, stream))) return rc;
         if ((rc = dense_gemm_kmajor(g_out, T, D, (const float *)d.proj_w, HD, dy, stream))) return rc;

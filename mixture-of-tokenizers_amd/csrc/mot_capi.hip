@@ -280,6 +280,8 @@ static int validate_cross_attn(const MotCrossAttnDesc *d) {
     if ((d->dim & 3) || d->dim > 1024) return set_error(MOT_EUNSUPPORTED, "cross_attn: dim %d must be a multiple of 4 and <= 1024", d->dim);
     if (d->matmul_dtype != MOT_F32 && d->matmul_dtype != MOT_BF16) return set_error(MOT_EINVAL, "cross_attn: bad matmul_dtype %d", d->matmul_dtype);
     if (d->matmul_dtype == MOT_BF16 && (d->dim & 7)) return set_error(MOT_EUNSUPPORTED, "cross_attn: matmul_dtype bf16 needs dim %% 8 == 0 (got %d)", d->dim);
+    if (d->io_dtype != MOT_F32 && !(d->io_dtype == MOT_BF16 && d->matmul_dtype == MOT_BF16))
+        return set_error(MOT_EINVAL, "cross_attn: io_dtype %d (bf16 out / grad_out go with matmul_dtype bf16)", d->io_dtype);
     if (d->head_layout != MOT_HEADS_AS_VIEWED && d->head_layout != MOT_HEADS_PER_TOKEN)
         return set_error(MOT_EINVAL, "cross_attn: bad head_layout %d", d->head_layout);
     if (!d->tokens || !d->ids_a || !d->tok_table || !d->byte_table || !d->q_w || !d->kv_w || !d->proj_w || !d->lambda_factor || !d->out)

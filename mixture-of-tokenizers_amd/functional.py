@@ -637,6 +637,7 @@ def _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, pro
     d.struct_size = C.sizeof(capi.MotCrossAttnDesc)
     d.dtype, d.n_tokens, d.bpt, d.n_heads, d.dim = capi.F32, T, int(bpt), int(n_heads), D
     d.matmul_dtype = capi.BF16 if mm_bf16 else capi.F32
+    d.io_dtype = capi.BF16 if (bf and mm_bf16) else capi.F32   # bf16 tables: the result and its gradient cross the boundary in bf16
     tt16 = None
     if bf and mm_bf16:   # the bf16 table itself: the normalised token rows are then gathered in bf16 directly
         tt16 = _contig(tok_table.detach(), torch.bfloat16, "tok_table")
@@ -692,7 +693,8 @@ def cross_attn_backward(grad_out, tokens, ids_a, tok_table, byte_table, *, q_w, 
         tokens = tokens[None]
     d, keep, dev, T, D = _cross_attn_desc(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj_w, lambda_factor, cos_q, sin_q, cos_k, sin_k,
                                           bpt, n_heads, norm_tok, norm_byte, head_layout, eps, matmul, widened)
-    g = _contig(grad_out.reshape(T, D).float(), torch.float32, "grad_out")
+    io = torch.bfloat16 if d.io_dtype == capi.BF16 else torch.float32
+    g = _contig(grad_out.reshape(T, D).to(io), io, "grad_out")
     out = {"tok_table": torch.zeros_like(keep[1]), "byte_table": torch.zeros_like(keep[2]), "q_w": torch.zeros_like(keep[3]),
            "kv_w": torch.zeros_like(keep[4]), "proj_w": torch.zeros_like(keep[5]), "lambda_factor": torch.zeros(1, dtype=torch.float32, device=dev)}
     gr = capi.MotCrossAttnGrads()
@@ -718,7 +720,7 @@ def _cross_attn_fwd(tokens, ids_a, ids_b, tok_table, byte_table, q_w, kv_w, proj
                                           wide_cache=None if kv_cache is None else kv_cache.setdefault("widened", {}))
     if _keep_widened is not None:
         _keep_widened.extend(keep[1:7])   # tt, bt, qw, kvw, pw, lam
-    out = torch.empty((1, T, D), dtype=torch.float32, device=dev)
+    out = torch.empty((1, T, D), dtype=torch.bfloat16 if d.io_dtype == capi.BF16 else torch.float32, device=dev)
     d.out = capi.ptr(out)
     if saved_qy is not None:
         d.saved_qy = capi.ptr(saved_qy)
