@@ -333,7 +333,7 @@ static int launch_attention(const AttnArgs &A, hipStream_t stream) {
 
 // ------------------------------------------------------------------------------------------ host
 // workspace, in floats: [q: T*HD][y: T*HD][kt: R*HD][vt: R*HD][xkv: R*D (dual: R = T*bpt)][xq: D > HD ? T*D : 0]
-struct AttnLayout { size_t q, y, kt, vt, xkv, xq, a16, w16, total; int64_t R; };
+struct AttnLayout { size_t q, y, kt, vt, xkv, xq, a16, w16, part, part_n, total; int64_t R; };
 // matmul_dtype == MOT_BF16: the two products over the tokens (q = W_q xq, out = c_proj y) run on the bf16 MFMA
 // (launch_gemm_rows_bf16, fp32 accumulation and fp32 results): their row operands are rounded to bf16 first -- the reference's own
 // rounding points in the production cast (xq is a bf16 tensor out of norm(), y one out of the attention, train_gpt.py:277, 292-293;
@@ -362,6 +362,8 @@ static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     const size_t a16 = dual && T * d.bpt * D > T * wide ? T * d.bpt * D : T * wide;
     L.a16 = take(mm16(d) ? (a16 + 1) / 2 : 0);
     L.w16 = take(mm16(d) ? ((dual ? 2 : 1) * HD * D + 1) / 2 : 0);
+    L.part_n = gemm_rows_sliced_floats(L.R, (int)D, (int)HD);   // the key / value projections of the few byte-table rows, cut along dim
+    L.part = take(L.part_n);
     L.total = o;
     return L;
 }
@@ -424,8 +426,10 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
             if ((rc = launch_gemm_rows_bf16(a16, D, L.R, w16, D, D, HD, kt, HD, false, nullptr, stream))) return rc;
             if ((rc = launch_gemm_rows_bf16(a16, D, L.R, w16 + (size_t)HD * D, D, D, HD, vt, HD, false, nullptr, stream))) return rc;
         } else {
-            if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w, (int)D, (int)D, (int)HD, kt, (int)HD, true, stream))) return rc;
-            if ((rc = launch_gemm_rows(xkv, (int)D, L.R, kv_w + (size_t)HD * D, (int)D, (int)D, (int)HD, vt, (int)HD, true, stream))) return rc;
+            // (one id tensor: 458 rows -- 24 output blocks of the plain kernel; cut along dim they fill the chip: 72 -> 15 us each)
+            if ((rc = launch_gemm_rows_sliced(xkv, (int)D, L.R, kv_w, (int)D, (int)D, (int)HD, kt, (int)HD, true, ws + L.part, L.part_n, stream))) return rc;
+            if ((rc = launch_gemm_rows_sliced(xkv, (int)D, L.R, kv_w + (size_t)HD * D, (int)D, (int)D, (int)HD, vt, (int)HD, true, ws + L.part, L.part_n, stream)))
+                return rc;
         }
         const int64_t kvw = L.R * H;
         hipLaunchKernelGGL(kv_finish_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kt, vt, L.R, H,
@@ -1002,7 +1006,7 @@ __global__ __launch_bounds__(kThreads) void iota_i32_kernel(int32_t *__restrict_
 
 // workspace of the backward, in floats
 struct AttnBwdLayout {
-    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, ids32b, emb, emb_bytes, b0, b1, w16, x16, dq16, total;
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, ids32b, emb, emb_bytes, b0, b1, w16, x16, dq16, part, part_n, total;
 };
 static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
     memset(&e, 0, sizeof(e));
@@ -1038,6 +1042,10 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     L.b0 = take(mm16(d) ? (T * wide + 1) / 2 : 0); L.b1 = take(mm16(d) ? (b1n + 1) / 2 : 0); L.w16 = take(mm16(d) ? ((dual ? 2 : 1) * HD * D + 1) / 2 : 0);
     L.x16 = take(mm16(d) && dual ? (P * D + 1) / 2 : 0);
     L.dq16 = take(mm16(d) ? (T * HD + 1) / 2 : 0);   // dq in bf16, written by the attention backward (b1 is reused for dkv in between)
+    // partial blocks of the few-row products (key / value projections; dxkv = dkv W_kv), see launch_gemm_rows_sliced
+    const size_t pa = gemm_rows_sliced_floats((int64_t)R, (int)D, (int)HD), pb = gemm_rows_sliced_floats((int64_t)R, (int)(2 * HD), (int)D);
+    L.part_n = pa > pb ? pa : pb;
+    L.part = take(L.part_n);
     L.total = o;
     return L;
 }
@@ -1045,8 +1053,9 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
 size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d) { return attn_bwd_layout(d).total * 4; }
 
 // out[n][Nout] = rows[n][Kc] . W[Kc][Nout]  (W with the reduction index as its row index): the plain dense MFMA kernel
-static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *W, int Nout, float *out, hipStream_t stream) {
-    return launch_gemm_rows(rows, Kc, n, W, Nout, Kc, Nout, out, Nout, false, stream);
+static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *W, int Nout, float *out, hipStream_t stream, float *part = nullptr,
+                             size_t part_n = 0) {
+    return launch_gemm_rows_sliced(rows, Kc, n, W, Nout, Kc, Nout, out, Nout, false, part, part_n, stream);
 }
 
 int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr, hipStream_t stream) {
@@ -1101,8 +1110,8 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         if ((rc = launch_gemm_rows_bf16(x16, D, R, w16k, D, D, HD, kpre, HD, false, nullptr, stream))) return rc;
         if ((rc = launch_gemm_rows_bf16(x16, D, R, w16k + (size_t)HD * D, D, D, HD, vpre, HD, false, nullptr, stream))) return rc;
     } else {
-        if ((rc = launch_gemm_rows(xkv, D, R, kv_w, D, D, HD, kpre, HD, true, stream))) return rc;
-        if ((rc = launch_gemm_rows(xkv, D, R, kv_w + (size_t)HD * D, D, D, HD, vpre, HD, true, stream))) return rc;
+        if ((rc = launch_gemm_rows_sliced(xkv, D, R, kv_w, D, D, HD, kpre, HD, true, ws + L.part, L.part_n, stream))) return rc;
+        if ((rc = launch_gemm_rows_sliced(xkv, D, R, kv_w + (size_t)HD * D, D, D, HD, vpre, HD, true, ws + L.part, L.part_n, stream))) return rc;
     }
     const int64_t kvw = R * H;
     hipLaunchKernelGGL(kv_norm_kernel, dim3((unsigned)((kvw + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, kpre, vpre, R, H, d.lambda_factor, eps, kn, vl);
@@ -1193,7 +1202,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         if (kv16) {
             if ((rc = launch_narrow_transpose(kv_w, 2 * HD, D, w16, stream))) return rc;   // [D][2 HD]
             if ((rc = launch_gemm_rows_bf16(b1, 2 * HD, R, w16, 2 * HD, 2 * HD, D, dxkv, D, false, nullptr, stream))) return rc;
-        } else if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;
+        } else if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream, ws + L.part, L.part_n))) return rc;
         int32_t *ids32b = (int32_t *)(ws + L.ids32b);
         hipLaunchKernelGGL(ids_to_i32_kernel, dim3(1024), dim3(kThreads), 0, stream, d.ids_b, P, (int64_t)d.byte_rows, ids32b);
         if ((rc = check_launch("ids_to_i32"))) return rc;
@@ -1212,7 +1221,7 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
         memset(&eg, 0, sizeof(eg));
         eg.struct_size = sizeof(eg);
     } else if (gr.d_byte_table) {
-        if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream))) return rc;   // kv_w as [2 HD, D]
+        if ((rc = dense_gemm_kmajor(dkv, R, 2 * HD, kv_w, D, dxkv, stream, ws + L.part, L.part_n))) return rc;   // kv_w as [2 HD, D]
         hipLaunchKernelGGL(byte_rows_bwd_kernel, dim3((unsigned)((R + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, (const float *)d.byte_table, dxkv, R, D,
                            d.norm_byte, eps, (float *)gr.d_byte_table);
         if ((rc = check_launch("byte_rows_bwd_kernel"))) return rc;

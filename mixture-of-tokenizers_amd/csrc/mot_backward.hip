@@ -2012,15 +2012,27 @@ __device__ __forceinline__ void gemm_rows_body(const float *__restrict__ A_, int
 
 // The register budget is set per variant: with B transposed the body fits 168 registers (3 waves per SIMD); with B in its
 // natural layout that cap spills inside the loop (0.92 ms instead of 0.72), so that variant runs at 2 waves per SIMD.
+// (blockIdx.y = slice of the reduction, `slice` indices long, whose block goes to C + y * part_stride: launch_gemm_rows_sliced)
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))) void gemm_rows_bt_kernel(
     const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb, int R, int Nc, float *__restrict__ C, int ldc,
-    const float *__restrict__ bias, int accumulate) {
-    gemm_rows_body<true>(A_, lda, n, B_, ldb, R, Nc, C, ldc, bias, accumulate);
+    const float *__restrict__ bias, int accumulate, int slice, int64_t part_stride) {
+    const int r0 = blockIdx.y * slice;
+    gemm_rows_body<true>(A_ + r0, lda, n, B_ + r0, ldb, slice ? min(slice, R - r0) : R, Nc, C + blockIdx.y * part_stride, ldc, bias, accumulate);
 }
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 4))) void gemm_rows_kernel(
     const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb, int R, int Nc, float *__restrict__ C, int ldc,
-    const float *__restrict__ bias, int accumulate) {
-    gemm_rows_body<false>(A_, lda, n, B_, ldb, R, Nc, C, ldc, bias, accumulate);
+    const float *__restrict__ bias, int accumulate, int slice, int64_t part_stride) {
+    const int r0 = blockIdx.y * slice;
+    gemm_rows_body<false>(A_ + r0, lda, n, B_ + (int64_t)r0 * ldb, ldb, slice ? min(slice, R - r0) : R, Nc, C + blockIdx.y * part_stride, ldc, bias, accumulate);
+}
+// C[i] = part[0][i] + part[1][i] + ... in that order (C rows ldc apart, the partial blocks dense [n][Nc])
+__global__ __launch_bounds__(kThreads) void gemm_rows_sum_slices_kernel(const float *__restrict__ part, int slices, int64_t n, int Nc, float *__restrict__ C, int ldc) {
+    const int64_t total = n * Nc;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        float v = part[i];
+        for (int s = 1; s < slices; ++s) v += part[(int64_t)s * total + i];
+        C[(i / Nc) * ldc + i % Nc] = v;
+    }
 }
 
 // (the reduction can be cut into launches that add to C; with the in-kernel blocked summation one launch covers any K)
@@ -2039,13 +2051,48 @@ int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int l
         const float *a = A_ + r0, *b = b_transposed ? B_ + r0 : B_ + (int64_t)r0 * ldb;
         if (b_transposed)
             hipLaunchKernelGGL(gemm_rows_bt_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
-                               r0 ? nullptr : bias, (r0 || accumulate) ? 1 : 0);
+                               r0 ? nullptr : bias, (r0 || accumulate) ? 1 : 0, 0, (int64_t)0);
         else
             hipLaunchKernelGGL(gemm_rows_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, lda, n, b, ldb, rn, Nc, C, ldc,
-                               r0 ? nullptr : bias, (r0 || accumulate) ? 1 : 0);
+                               r0 ? nullptr : bias, (r0 || accumulate) ? 1 : 0, 0, (int64_t)0);
         if (r0 + kGemmRowsPass >= R) break;
     }
     return check_launch("gemm_rows_kernel");
+}
+
+// how the reduction of a few-row product is cut: slices of a multiple of 16 indices, at least 64, as many as fill the chip once
+static int gemm_rows_slices(int64_t n, int R, int Nc, int *slice_len) {
+    const int64_t blocks = ((n + 127) / 128 + 7) / 8 * 8 * ((Nc + 127) / 128), live = ((n + 127) / 128) * ((Nc + 127) / 128);
+    if (n > 1024 || R < 256 || live >= 128 || blocks > 4096) return 1;
+    int want = (int)(256 / live);
+    if (want > R / 64) want = R / 64;
+    if (want > 16) want = 16;
+    if (want < 2) return 1;
+    const int len = ((R + want - 1) / want + 15) / 16 * 16;
+    *slice_len = len;
+    return (R + len - 1) / len;
+}
+size_t gemm_rows_sliced_floats(int64_t n, int R, int Nc) {
+    int len = 0;
+    const int s = gemm_rows_slices(n, R, Nc, &len);
+    return s > 1 ? (size_t)s * n * Nc : 0;
+}
+int launch_gemm_rows_sliced(const float *A_, int lda, int64_t n, const float *B_, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed, float *part,
+                            size_t part_floats, hipStream_t stream) {
+    int len = 0;
+    const int slices = n > 0 && Nc > 0 ? gemm_rows_slices(n, R, Nc, &len) : 1;
+    if (slices < 2 || !part || part_floats < (size_t)slices * n * Nc) return launch_gemm_rows(A_, lda, n, B_, ldb, R, Nc, C, ldc, b_transposed, stream);
+    const int64_t blocks = ((n + 127) / 128 + 7) / 8 * 8 * ((Nc + 127) / 128);
+    const dim3 grid((unsigned)blocks, (unsigned)slices);
+    if (b_transposed)
+        hipLaunchKernelGGL(gemm_rows_bt_kernel, grid, dim3(kThreads), 0, stream, A_, lda, n, B_, ldb, R, Nc, part, Nc, (const float *)nullptr, 0, len, n * Nc);
+    else
+        hipLaunchKernelGGL(gemm_rows_kernel, grid, dim3(kThreads), 0, stream, A_, lda, n, B_, ldb, R, Nc, part, Nc, (const float *)nullptr, 0, len, n * Nc);
+    if (int rc = check_launch("gemm_rows_kernel")) return rc;
+    const int64_t total = n * Nc;
+    hipLaunchKernelGGL(gemm_rows_sum_slices_kernel, dim3((unsigned)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048)), dim3(kThreads), 0,
+                       stream, part, slices, n, Nc, C, ldc);
+    return check_launch("gemm_rows_sum_slices_kernel");
 }
 
 // workspace of the CONCAT backward, in floats unless noted:

@@ -55,6 +55,12 @@ int launch_gemm_tn(const float *A, int lda, int M, const float *B, int ldb, int 
 // C[n][c] = sum_r A[n][r] * (b_transposed ? B[c][r] : B[r][c]) (+ bias[c]), fp32 MFMA, plain stores
 int launch_gemm_rows(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed, hipStream_t stream,
                      const float *bias = nullptr, bool accumulate = false);
+// the same product for FEW rows (a 458-row byte table, 132 character rows) over a long reduction: the reduction is cut into slices,
+// one workgroup per (output block, slice), whose partial blocks go to `part` (gemm_rows_sliced_floats(n, R, Nc) floats, 0 = the shape
+// gains nothing) and are summed in slice order by a second kernel -- the same bits on every run.  Falls back to launch_gemm_rows.
+size_t gemm_rows_sliced_floats(int64_t n, int R, int Nc);
+int launch_gemm_rows_sliced(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc, float *C, int ldc, bool b_transposed, float *part,
+                            size_t part_floats, hipStream_t stream);
 // the composed concat + linear forward (index kernels, seam gather, dense MFMA kernel, row norm), fp32 and bf16 (mot_linear.hip)
 bool embed_mix_linear_is_composed(const MotEmbedMixDesc &d);
 size_t embed_mix_linear_composed_workspace_bytes(const MotEmbedMixDesc &d);

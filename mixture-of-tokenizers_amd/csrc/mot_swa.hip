@@ -159,7 +159,8 @@ size_t char_swa_workspace_bytes(const MotCharSwaDesc &d) {
     const size_t hdim = (size_t)d.n_heads * d.head_dim;
     // [cn: char_rows x dim][K, V: char_rows x hdim each][xn | y: slab x max(dim, hdim)][q: slab x hdim][byte_rnorm scratch of the residual call]
     size_t fl = swa_align((size_t)d.char_rows * d.dim) + 2 * swa_align((size_t)d.char_rows * hdim) +
-                swa_align((size_t)slab * (d.dim > (int)hdim ? d.dim : hdim)) + swa_align((size_t)slab * hdim) + swa_align(d.char_rows);
+                swa_align((size_t)slab * (d.dim > (int)hdim ? d.dim : hdim)) + swa_align((size_t)slab * hdim) + swa_align(d.char_rows) +
+                swa_align(gemm_rows_sliced_floats(d.char_rows, d.dim, (int)hdim));   // partial blocks of the key / value projections
     if (d.matmul_dtype == MOT_BF16)   // bf16 copies: the row operand of a product (xn, then y), wq, wo
         fl += swa_align(((size_t)slab * (d.dim > (int)hdim ? d.dim : hdim) + 1) / 2) + 2 * swa_align((hdim * (size_t)d.dim + 1) / 2);
     return fl * sizeof(float);
@@ -176,10 +177,12 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
     float *xn = vt + swa_align((size_t)d.char_rows * hdim), *yb = xn;   // the attention output reuses the normalised rows' buffer
     float *qb = xn + swa_align((size_t)slab * (d.dim > hdim ? d.dim : hdim));
     float *rn_scratch = qb + swa_align((size_t)slab * hdim);
+    const size_t part_n = gemm_rows_sliced_floats(d.char_rows, d.dim, hdim);
+    float *part = rn_scratch + swa_align(d.char_rows);
     // matmul_dtype == MOT_BF16: the two products over the tokens on the bf16 MFMA (fp32 sums and results), their row operands and
     // weights narrowed to bf16 first (the weights once per call)
     const bool mm16 = d.matmul_dtype == MOT_BF16;
-    float *a16 = rn_scratch + swa_align(d.char_rows);
+    float *a16 = part + swa_align(part_n);
     float *wq16 = a16 + swa_align(((size_t)slab * (d.dim > hdim ? d.dim : hdim) + 1) / 2), *wo16 = wq16 + swa_align(((size_t)hdim * d.dim + 1) / 2);
     const float eps = d.norm_eps > 0.f ? d.norm_eps : 1e-5f;   // ModelArgs.norm_eps default, inference.py:43
     int rc;
@@ -197,8 +200,9 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
                            (const int64_t *)nullptr, (int64_t)d.char_rows, (const float *)d.char_table, (int64_t)d.char_rows, d.dim,
                            (const float *)d.char_norm_w, eps, cn, d.status, kStatusByteOor);
         if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
-        if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wk, d.dim, d.dim, hdim, kt, hdim, true, stream))) return rc;
-        if ((rc = launch_gemm_rows(cn, d.dim, d.char_rows, (const float *)d.wv, d.dim, d.dim, hdim, vt, hdim, true, stream))) return rc;
+        // (132 rows: 32 output blocks of the plain kernel, each 128 steps deep; cut along dim they fill the chip)
+        if ((rc = launch_gemm_rows_sliced(cn, d.dim, d.char_rows, (const float *)d.wk, d.dim, d.dim, hdim, kt, hdim, true, part, part_n, stream))) return rc;
+        if ((rc = launch_gemm_rows_sliced(cn, d.dim, d.char_rows, (const float *)d.wv, d.dim, d.dim, hdim, vt, hdim, true, part, part_n, stream))) return rc;
     }
     const size_t lds = ((size_t)d.char_rows * (d.head_dim + 4) + (size_t)d.char_rows * d.head_dim + 2 * 64 * kSwaWaves) * sizeof(float);
     if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "char_swa: %d character rows x head_dim %d need %zu B of LDS (> 160 KiB)", d.char_rows, d.head_dim, lds);
