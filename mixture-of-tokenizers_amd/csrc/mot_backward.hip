@@ -2060,13 +2060,13 @@ int launch_gemm_rows(const float *A_, int lda, int64_t n, const float *B_, int l
     return check_launch("gemm_rows_kernel");
 }
 
-// how the reduction of a few-row product is cut: slices of a multiple of 16 indices, at least 64, as many as fill the chip once
+// how the reduction of a few-row product is cut: slices of a multiple of 16 indices, at least 64, as many as fill the chip
 static int gemm_rows_slices(int64_t n, int R, int Nc, int *slice_len) {
     const int64_t blocks = ((n + 127) / 128 + 7) / 8 * 8 * ((Nc + 127) / 128), live = ((n + 127) / 128) * ((Nc + 127) / 128);
     if (n > 1024 || R < 256 || live >= 128 || blocks > 4096) return 1;
-    int want = (int)(256 / live);
+    int want = (int)(768 / live);   // (three workgroups a CU: a step of this kernel is one exposed load latency, ~5 us of it per step measured)
     if (want > R / 64) want = R / 64;
-    if (want > 16) want = 16;
+    if (want > 32) want = 32;
     if (want < 2) return 1;
     const int len = ((R + want - 1) / want + 15) / 16 * 16;
     *slice_len = len;

@@ -62,6 +62,8 @@ def test_cross_attn_modules_vs_reference(mot, case, mode):
     (1024, 16, 2048, 130, "as_viewed", False, 9903),     # production dims: 8 heads
     (256, 5, 512, 77, "as_viewed", True, 9904),          # two id tensors: keys depend on the id pair
     (384, 7, 300, 33, "per_token", True, 9905),
+    (768, 20, 512, 50, "as_viewed", False, 9906),        # more than 16 keys: the key-loop attention kernel
+    (768, 11, 512, 50, "as_viewed", False, 9907),        # an odd key count in the lane-per-(key, quarter) kernel
 ])
 def test_cross_attn_vs_oracle(mot, D, bpt, Vt, T, layout, dual, seed):
     from mixture_of_tokenizers_amd.modules import Rotary
@@ -144,6 +146,9 @@ def test_cross_attn_backward_vs_reference_autograd(mot, case, mode):
     (640, 7, 300, 53, "as_viewed", True, 9955, False),         # 5 heads: the per-head-slice variant of the table-row reduction
     (640, 7, 300, 53, "per_token", True, 9956, False),
     (384, 3, 300, 41, "per_token", False, 9957, False),        # 3 heads, bpt smaller than the head count
+    (768, 4, 300, 45, "as_viewed", True, 9958, False),         # 6 heads, 4 keys: the slots of a position run over more than two queries
+    (768, 20, 300, 37, "as_viewed", True, 9959, False),        # more than 16 keys: the key-loop attention kernels
+    (256, 20, 300, 37, "per_token", True, 9960, True),
     # two id tensors (add_padded_and_pulled, train_gpt.py:364-372): key / value rows per kv position
     (768, 16, 4096, 150, "as_viewed", True, 9961, True),
     (768, 16, 4096, 150, "per_token", True, 9962, True),
