@@ -68,24 +68,40 @@ __global__ __launch_bounds__(kThreads) void rows_rmsnorm_w_kernel(const IdT *__r
 //           readlanes per key and element-per-lane value reads: 4.7 ms per 65 536 tokens x 32 heads.)
 constexpr int kSwaThreads = 512, kSwaWaves = kSwaThreads / 64;   // 8 waves share one copy of K_h / V_h: two workgroups = 16 waves per CU
 
-template <int HDL>   // head_dim = 64 * HDL
+// (KV16: the key / value rows sit in LDS as bf16 and `q` points to bf16 queries -- with bf16 tables and weights q = wq xn, k = wk cn and
+//  v = wv cn ARE bf16 tensors in the reference, and the LDS reads of the key / value rows are what bounds the kernel: 33 KB per
+//  (token, head) in fp32, all four SIMDs on one LDS)
+__device__ __forceinline__ uint32_t swa_pack2(float a, float b) {
+    return (uint32_t)__builtin_bit_cast(unsigned short, (__bf16)a) | ((uint32_t)__builtin_bit_cast(unsigned short, (__bf16)b) << 16);
+}
+__device__ __forceinline__ float swa_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float swa_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int HDL, bool KV16>   // head_dim = 64 * HDL
 __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__restrict__ q, const float *__restrict__ ktab, const float *__restrict__ vtab,
                                                             const int64_t *__restrict__ char_ids, int64_t n0, int64_t n_tok, int64_t T, int c_v, int window,
                                                             int char_rows, int n_heads, int tile_tokens, float *__restrict__ y, uint32_t *status,
                                                             __bf16 *__restrict__ y16) {   // y16: y is written there in bf16 instead (row operand of wo on the bf16 MFMA)
-    constexpr int HD = 64 * HDL, KS = HD + 4;                    // key rows padded by 16 bytes: lanes reading different rows spread over the banks
+    constexpr int HD = 64 * HDL;
+    constexpr int KS = (KV16 ? HD / 2 : HD) + 4, VS = KV16 ? HD / 2 : HD;   // row strides in dwords; key rows padded by 16 bytes: lanes reading different rows spread over the banks
     constexpr int QUADS = HD / 4, GROUPS = 64 / QUADS;           // 16 x 4 at head_dim 64, 32 x 2 at 128
     extern __shared__ __attribute__((aligned(16))) float lds_kv[];
     float *lk = lds_kv, *lv = lds_kv + (size_t)char_rows * KS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float2 *pid = (float2 *)(lv + (size_t)char_rows * HD) + wave * 64;   // this wave's (p, id) strip
+    float2 *pid = (float2 *)(lv + (size_t)char_rows * VS) + wave * 64;   // this wave's (p, id) strip
     const int h = blockIdx.y;
     const int HDIM = n_heads * HD;
     for (int i = tid; i < char_rows * (HD / 4); i += kSwaThreads) {
         const int r = i / (HD / 4), c = (i - r * (HD / 4)) * 4;
-        *(float4v *)(lk + r * KS + c) = *(const float4v *)(ktab + (int64_t)r * HDIM + h * HD + c);
-        *(float4v *)(lv + r * HD + c) = *(const float4v *)(vtab + (int64_t)r * HDIM + h * HD + c);
+        const float4v kk = *(const float4v *)(ktab + (int64_t)r * HDIM + h * HD + c), vv = *(const float4v *)(vtab + (int64_t)r * HDIM + h * HD + c);
+        if (KV16) {
+            *(uint2 *)(lk + r * KS + c / 2) = uint2{swa_pack2(kk.x, kk.y), swa_pack2(kk.z, kk.w)};
+            *(uint2 *)(lv + r * VS + c / 2) = uint2{swa_pack2(vv.x, vv.y), swa_pack2(vv.z, vv.w)};
+        } else {
+            *(float4v *)(lk + r * KS + c) = kk;
+            *(float4v *)(lv + r * VS + c) = vv;
+        }
     }
     __syncthreads();
     const int nkeys = window * c_v;
@@ -112,13 +128,28 @@ __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__re
         const float *qrow = q + tl * HDIM + h * HD;
         const float *krow = lk + id * KS;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;           // four chains: a single one is 64 dependent fmas deep
+        if (KV16) {
+            // (the query is a bf16 tensor too -- written so by its product -- and arrives as scalar pairs: v_dot2c_f32_bf16, one
+            //  instruction per two dims where unpacking the key pairs for fp32 multiply-adds took four)
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const uint32_t *q2 = (const uint32_t *)q + ((tl * HDIM + h * HD) >> 1);
 #pragma unroll
-        for (int d4 = 0; d4 < HD / 4; ++d4) {
-            const float4v kk = *(const float4v *)(krow + 4 * d4);
-            s0 += qrow[4 * d4 + 0] * kk.x;
-            s1 += qrow[4 * d4 + 1] * kk.y;
-            s2 += qrow[4 * d4 + 2] * kk.z;
-            s3 += qrow[4 * d4 + 3] * kk.w;
+            for (int d8 = 0; d8 < HD / 8; ++d8) {
+                const uint4 u = *(const uint4 *)(krow + 4 * d8);
+                s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 0]), __builtin_bit_cast(bf16x2, u.x), s0, false);
+                s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 1]), __builtin_bit_cast(bf16x2, u.y), s1, false);
+                s2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 2]), __builtin_bit_cast(bf16x2, u.z), s2, false);
+                s3 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 3]), __builtin_bit_cast(bf16x2, u.w), s3, false);
+            }
+        } else {
+#pragma unroll
+            for (int d4 = 0; d4 < HD / 4; ++d4) {
+                const float4v kk = *(const float4v *)(krow + 4 * d4);
+                s0 += qrow[4 * d4 + 0] * kk.x;
+                s1 += qrow[4 * d4 + 1] * kk.y;
+                s2 += qrow[4 * d4 + 2] * kk.z;
+                s3 += qrow[4 * d4 + 3] * kk.w;
+            }
         }
         const float s = real ? ((s0 + s1) + (s2 + s3)) * scale : 0.f;
         // ---- softmax over the nkeys keys (padding keys included, score 0)
@@ -134,8 +165,13 @@ __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__re
 #pragma unroll 4
         for (int j = g; j < 64; j += GROUPS) {
             const float2 pi = pid[j];
-            const float4v vv = *(const float4v *)(lv + __float_as_int(pi.y) * HD + 4 * dq);
-            acc += pi.x * vv;
+            if (KV16) {
+                const uint2 u = *(const uint2 *)(lv + __float_as_int(pi.y) * VS + 2 * dq);
+                acc += pi.x * float4v{swa_lo(u.x), swa_hi(u.x), swa_lo(u.y), swa_hi(u.y)};
+            } else {
+                const float4v vv = *(const float4v *)(lv + __float_as_int(pi.y) * VS + 4 * dq);
+                acc += pi.x * vv;
+            }
         }
 #pragma unroll
         for (int o = QUADS; o < 64; o <<= 1) {
@@ -204,7 +240,9 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
         if ((rc = launch_gemm_rows_sliced(cn, d.dim, d.char_rows, (const float *)d.wk, d.dim, d.dim, hdim, kt, hdim, true, part, part_n, stream))) return rc;
         if ((rc = launch_gemm_rows_sliced(cn, d.dim, d.char_rows, (const float *)d.wv, d.dim, d.dim, hdim, vt, hdim, true, part, part_n, stream))) return rc;
     }
-    const size_t lds = ((size_t)d.char_rows * (d.head_dim + 4) + (size_t)d.char_rows * d.head_dim + 2 * 64 * kSwaWaves) * sizeof(float);
+    // (matmul_dtype == MOT_BF16: the key / value rows are bf16 tensors in the reference's bf16 cast and are kept as such in LDS)
+    const int row_dw = mm16 ? d.head_dim / 2 : d.head_dim;
+    const size_t lds = ((size_t)d.char_rows * (row_dw + 4) + (size_t)d.char_rows * row_dw + 2 * 64 * kSwaWaves) * sizeof(float);
     if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "char_swa: %d character rows x head_dim %d need %zu B of LDS (> 160 KiB)", d.char_rows, d.head_dim, lds);
     for (int64_t n0 = 0; n0 < N; n0 += slab) {
         const int64_t nn = N - n0 < slab ? N - n0 : slab;
@@ -214,23 +252,22 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
                            (const float *)d.tok_table, d.tok_rows, d.dim, (const float *)d.attn_norm_w, eps, xn, d.status, kStatusTokenOor,
                            mm16 ? (__bf16 *)a16 : nullptr);
         if ((rc = check_launch("rows_rmsnorm_w_kernel"))) return rc;
-        if (mm16) {   // (the normalised rows and, below, the attention output arrive in bf16: no narrowing passes)
-            if ((rc = launch_gemm_rows_bf16(a16, d.dim, nn, wq16, d.dim, d.dim, hdim, qb, hdim, false, nullptr, stream))) return rc;
+        if (mm16) {   // (the normalised rows and, below, the attention output arrive in bf16: no narrowing passes; q leaves its product in bf16)
+            if ((rc = launch_gemm_rows_bf16(a16, d.dim, nn, wq16, d.dim, d.dim, hdim, qb, hdim, true, nullptr, stream))) return rc;
         } else if ((rc = launch_gemm_rows(xn, d.dim, nn, (const float *)d.wq, d.dim, d.dim, hdim, qb, hdim, true, stream))) return rc;
         // ---- attention
         const int tile = 256;
         const dim3 grid((unsigned)((nn + tile - 1) / tile), (unsigned)d.n_heads);
-        if (d.head_dim == 64) {
-            static std::atomic<uint64_t> lds_ok{0};
-            if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<1>, lds_ok, "char_swa_kernel"))) return rc;
-            hipLaunchKernelGGL(char_swa_kernel<1>, grid, dim3(kSwaThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
-                               d.char_rows, d.n_heads, tile, yb, d.status, mm16 ? (__bf16 *)a16 : nullptr);
-        } else {
-            static std::atomic<uint64_t> lds_ok{0};
-            if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<2>, lds_ok, "char_swa_kernel"))) return rc;
-            hipLaunchKernelGGL(char_swa_kernel<2>, grid, dim3(kSwaThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, d.c_v, d.window,
-                               d.char_rows, d.n_heads, tile, yb, d.status, mm16 ? (__bf16 *)a16 : nullptr);
-        }
+#define MOT_SWA_LAUNCH(HDL, KV16)                                                                                                             \
+    do {                                                                                                                                      \
+        static std::atomic<uint64_t> lds_ok{0};                                                                                               \
+        if ((rc = ensure_max_dyn_lds((const void *)char_swa_kernel<HDL, KV16>, lds_ok, "char_swa_kernel"))) return rc;                         \
+        hipLaunchKernelGGL((char_swa_kernel<HDL, KV16>), grid, dim3(kSwaThreads), lds, stream, qb, kt, vt, d.char_ids, n0, nn, d.tokens_per_row, \
+                           d.c_v, d.window, d.char_rows, d.n_heads, tile, yb, d.status, mm16 ? (__bf16 *)a16 : nullptr);                      \
+    } while (0)
+        if (d.head_dim == 64) { if (mm16) MOT_SWA_LAUNCH(1, true); else MOT_SWA_LAUNCH(1, false); }
+        else { if (mm16) MOT_SWA_LAUNCH(2, true); else MOT_SWA_LAUNCH(2, false); }
+#undef MOT_SWA_LAUNCH
         if ((rc = check_launch("char_swa_kernel"))) return rc;
         // ---- residuals first (they overwrite `out`), then out += wo y
         bool accumulate = false;

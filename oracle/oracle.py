@@ -380,7 +380,8 @@ def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, 
     TokenMixByCharBMMBlock.forward up to `h` (260-267) -> TokenMixByCharBMM.forward (189-238, swa_transform 174-179).
     tokens (B, T), char_ids (B, T, c_v).  PARITY UNPINNED (see the section header).  numpy, small sizes only.
     round_token_products_bf16: the row operands of the two products over the tokens (the normalised token rows in front of wq,
-    the attention output in front of wo) are rounded to bf16 -- what the HIP path does with matmul_dtype = MOT_BF16."""
+    the attention output in front of wo) and the projected queries, keys and values (bf16 tensors out of wq / wk / wv in the
+    reference's bf16 cast) are rounded to bf16 -- what the HIP path does with matmul_dtype = MOT_BF16."""
     f = np.float64
     tok_table, char_table = np.asarray(tok_table, f), np.asarray(char_table, f)
     toks = tok_table[np.asarray(tokens)]                                   # (b, t, d)        line 323
@@ -391,7 +392,11 @@ def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, 
     if round_token_products_bf16:
         x = np.asarray(bf16_round(x), f)
     xq = x @ np.asarray(wq, f).T                                            # (b, t, bmm)      199
+    if round_token_products_bf16:
+        xq = np.asarray(bf16_round(xq), f)
     xk, xv = cn @ np.asarray(wk, f).T, cn @ np.asarray(wv, f).T             # (b, t, c_v, bmm) 200
+    if round_token_products_bf16:
+        xk, xv = np.asarray(bf16_round(xk), f), np.asarray(bf16_round(xv), f)
 
     def swa(a):                                                             # 174-179
         pad = np.zeros((b, window - 1, c_v, a.shape[-1]), f)

@@ -132,9 +132,10 @@ def test_char_swa_across_slabs(mot):
 def test_char_swa_bf16_tables(mot, matmul, T):
     """bf16 tables and weights: operands widened once, one rounding of the result -- held to the float64 oracle evaluated on the
     bf16 VALUES, within one bf16 step (parity unpinned, as everything of this file).  matmul="fp32": all of it on the fp32 kernels.
-    matmul=None (what bf16 tables select): the two products over the tokens on the bf16 MFMA, their row operands rounded to bf16 --
-    the oracle rounds the same two operands (round_token_products_bf16): > 99.9 % within one step, all within one step of the larger
-    of the output and the outputs' rms; against the oracle without those roundings: three such steps."""
+    matmul=None (what bf16 tables select): the two products over the tokens on the bf16 MFMA, their row operands rounded to bf16, and
+    the projected keys / values kept in bf16 (as the reference's bf16 cast has them) -- the oracle rounds the same four tensors
+    (round_token_products_bf16): > 99.5 % within one step, all within 1.5 steps of the larger of the output and the outputs' rms;
+    against the oracle without those roundings: three such steps."""
     B, c_v, d, H, hd, window = 2, 8, 256, 4, 64, 8
     c = case(21, B, T, c_v, d, H, hd, 700, 132)
     c16 = {k: (orc.bf16_round(v) if v.dtype == np.float32 else v) for k, v in c.items()}
@@ -153,10 +154,11 @@ def test_char_swa_bf16_tables(mot, matmul, T):
         assert (steps(oracle()) <= 1).all()
     else:
         # (an element of xn or y that sits on a bf16 rounding boundary can round the other way in fp32 than in float64 and moves an
-        #  output by |w| 2^-8 |y|: a second step for a handful of outputs)
+        #  output by |w| 2^-8 |y|: a second step for a handful of outputs; an element of a key or value row that does moves every output
+        #  whose token attends to that character a little: measured 99.72 % within one step and 1.04 steps at most at 660 tokens)
         emul = oracle(round_token_products_bf16=True)
         em = steps(emul)
-        assert (np.abs(got - emul) <= 2.0 ** -8 * np.maximum(np.abs(emul), np.sqrt((emul ** 2).mean()))).all() and (em <= 1).mean() > 0.999, \
+        assert (np.abs(got - emul) <= 1.5 * 2.0 ** -8 * np.maximum(np.abs(emul), np.sqrt((emul ** 2).mean()))).all() and (em <= 1).mean() > 0.995, \
             (em.max(), (em <= 1).mean())
         plain = oracle()   # without the two roundings: they move an output by ~2^-9 of the TYPICAL size of h, whatever its own size
         assert (np.abs(got - plain) <= 3 * 2.0 ** -8 * np.maximum(np.abs(plain), np.sqrt((plain ** 2).mean()))).all()
