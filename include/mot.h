@@ -427,6 +427,11 @@ typedef struct MotCharSwaDesc {
      * table.  They depend on char_table, char_norm_w, wk and wv only, so an inference loop (what the reference file is) builds them
      * once: pass the buffer with kv_tables_ready = 0 after those change (the call fills it), = 1 otherwise. */
     void *kv_tables;
+    /* MOT_F32 (0) or, with matmul_dtype == MOT_BF16, MOT_BF16: the element type of `out`.  bf16 is what the module returns in a bf16
+     * cast: the last product then adds the fp32 residuals and writes bf16 itself (one rounding, as a caller's cast of the fp32 result
+     * would do; a pass over [B, T, dim] less on each side of the boundary). */
+    int32_t io_dtype;
+    int32_t reserved1;   /* must be 0 */
 } MotCharSwaDesc;
 
 size_t mot_char_swa_desc_size(void);

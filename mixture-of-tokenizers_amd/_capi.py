@@ -119,7 +119,7 @@ class MotCharSwaDesc(C.Structure):
         ("attn_norm_w", C.c_void_p), ("char_norm_w", C.c_void_p), ("wq", C.c_void_p), ("wk", C.c_void_p), ("wv", C.c_void_p), ("wo", C.c_void_p),
         ("lambda_tok", C.c_void_p), ("lambda_char", C.c_void_p), ("out", C.c_void_p), ("status", C.c_void_p),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("matmul_dtype", C.c_int32), ("kv_tables_ready", C.c_int32),
-        ("kv_tables", C.c_void_p),
+        ("kv_tables", C.c_void_p), ("io_dtype", C.c_int32), ("reserved1", C.c_int32),
     ]
 
 

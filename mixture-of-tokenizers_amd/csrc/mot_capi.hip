@@ -242,6 +242,8 @@ static int validate_char_swa(const MotCharSwaDesc *d) {
     if (d->matmul_dtype != MOT_F32 && d->matmul_dtype != MOT_BF16) return set_error(MOT_EINVAL, "char_swa: bad matmul_dtype %d", d->matmul_dtype);
     if (d->matmul_dtype == MOT_BF16 && ((d->dim & 7) || ((d->n_heads * d->head_dim) & 7)))
         return set_error(MOT_EUNSUPPORTED, "char_swa: matmul_dtype bf16 needs dim and heads * head_dim to be multiples of 8");
+    if ((d->io_dtype != MOT_F32 && !(d->io_dtype == MOT_BF16 && d->matmul_dtype == MOT_BF16)) || d->reserved1)
+        return set_error(MOT_EINVAL, "char_swa: io_dtype %d (a bf16 result goes with matmul_dtype bf16) / reserved1 %d", d->io_dtype, d->reserved1);
     if (!d->tokens || !d->char_ids || !d->tok_table || !d->char_table || !d->attn_norm_w || !d->char_norm_w || !d->wq || !d->wk || !d->wv || !d->wo || !d->out)
         return set_error(MOT_EINVAL, "char_swa: tokens/char_ids/tables/norm weights/projections/out must be non-null");
     if (d->tok_rows <= 0 || d->char_rows <= 0) return set_error(MOT_ESHAPE, "char_swa: empty table");

@@ -23,7 +23,7 @@ constexpr int kGRow = 2 * kGK + 16; // bytes per staged row
 
 template <bool OUT_BF16, int WM>   // WM waves along the rows x 2 along the columns: a (64 WM) x 128 output block per workgroup
 __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3, 4))) void gemm_rows_bf16_kernel(const __bf16 *__restrict__ A_, int lda, int64_t n, const __bf16 *__restrict__ B_, int ldb,
-                                                                  int R, int Nc, void *__restrict__ C_, int ldc, const __bf16 *__restrict__ bias, int accumulate) {
+                                                                  int R, int Nc, void *__restrict__ C_, int ldc, const __bf16 *__restrict__ bias, const float *__restrict__ addend) {
     constexpr int TM = 64 * WM, NTHR = 128 * WM, PA = TM * 4 / NTHR, PB = (128 * 4 + NTHR - 1) / NTHR;
     __shared__ __attribute__((aligned(16))) char lA[2][TM * kGRow], lB[2][128 * kGRow];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, li = lane & 31;
@@ -120,9 +120,10 @@ __global__ __launch_bounds__(128 * WM) __attribute__((amdgpu_waves_per_eu(3, 4))
             for (int r = 0; r < 16; ++r) {
                 const int64_t j = j0 + wm + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (j < n && k < Nc) {
-                    const float v = acc[a][b][r] + bv;
+                    float v = acc[a][b][r] + bv;
+                    if (addend) v += addend[j * ldc + k];   // (C += : addend = C; a bf16 result on top of an fp32 residual: another buffer, same rows)
                     if constexpr (OUT_BF16) ((__bf16 *)C_)[j * ldc + k] = (__bf16)v;
-                    else ((float *)C_)[j * ldc + k] = accumulate ? ((const float *)C_)[j * ldc + k] + v : v;   // (C += : fp32 results only)
+                    else ((float *)C_)[j * ldc + k] = v;
                 }
             }
         }
@@ -162,7 +163,7 @@ __device__ __forceinline__ void static_for_g(F &&f) {
 // concat parity bar (twice the reference's own fp32 error) needs at K = 768.
 template <typename E, bool OUT_BF16, int MT, int NT, int WC>
 __global__ __launch_bounds__(kG2Threads) void gemm_rows_256_kernel(const E *__restrict__ A_, int lda, int64_t n, const E *__restrict__ B_, int ldb,
-                                                                   int R, int Nc, void *__restrict__ C_, int ldc, const E *__restrict__ bias, int accumulate) {
+                                                                   int R, int Nc, void *__restrict__ C_, int ldc, const E *__restrict__ bias, const float *__restrict__ addend) {
     constexpr int EPR = 64 / (int)sizeof(E), EPP = 16 / (int)sizeof(E);   // elements per stage row / per 16-byte piece
     constexpr int BM = (8 / WC) * 32 * MT, BN = WC * 32 * NT, kStage = (BM + BN) * 64, NA = BM / 128, NB = BN / 128, ND = NA + NB;
     constexpr bool kFoldSums = std::is_same_v<E, float>;
@@ -305,8 +306,9 @@ __global__ __launch_bounds__(kG2Threads) void gemm_rows_256_kernel(const E *__re
                 if (j < n) {
                     float v = acc[a][b][r] + bv;
                     if constexpr (kFoldSums) v = (sum[a][b][r] + acc[a][b][r]) + bv;
+                    if (addend) v += addend[j * ldc + k];
                     if constexpr (OUT_BF16) ((__bf16 *)C_)[j * ldc + k] = (__bf16)v;
-                    else ((float *)C_)[j * ldc + k] = accumulate ? ((const float *)C_)[j * ldc + k] + v : v;
+                    else ((float *)C_)[j * ldc + k] = v;
                 }
             }
         }
@@ -329,14 +331,15 @@ int launch_gemm_rows_f32_256(const float *A_, int lda, int64_t n, const float *B
     static std::atomic<uint64_t> ok{0};
     if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_256_kernel<float, false, 2, 2, 2>, ok, "gemm_rows_256_kernel")) return rc;
     hipLaunchKernelGGL((gemm_rows_256_kernel<float, false, 2, 2, 2>), dim3((unsigned)blocks2), dim3(kG2Threads), (size_t)kG2NS * (256 + 128) * 64, stream, A_, lda, n,
-                       B_, ldb, R, Nc, (void *)C, ldc, bias, accumulate ? 1 : 0);
+                       B_, ldb, R, Nc, (void *)C, ldc, bias, accumulate ? (const float *)C : (const float *)nullptr);
     return check_launch("gemm_rows_256_kernel");
 }
 
 int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
-                          const void *bias, hipStream_t stream, bool accumulate) {
+                          const void *bias, hipStream_t stream, bool accumulate, const float *addend) {
     if (n <= 0 || Nc <= 0) return MOT_OK;
     if (accumulate && out_bf16) return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: C += needs an fp32 result");
+    if (accumulate) addend = (const float *)C;
     if ((R & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A_ & 15) || ((uintptr_t)B_ & 15))
         return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: rows must be 16-byte aligned multiples of 8 elements (R %d, lda %d, ldb %d)", R, lda, ldb);
     bool big = (Nc % 256) == 0 && (R % 32) == 0 && n >= 512 && (int64_t)256 * (lda > ldb ? lda : ldb) * 2 < 0x7fffffffLL;
@@ -351,11 +354,11 @@ int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, in
         if (out_bf16) {
             if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_256_kernel<__bf16, true, 4, 2, 4>, ok1, "gemm_rows_256_kernel")) return rc;
             hipLaunchKernelGGL((gemm_rows_256_kernel<__bf16, true, 4, 2, 4>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
-                               (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, 0);
+                               (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, addend);
         } else {
             if (int rc = ensure_max_dyn_lds((const void *)gemm_rows_256_kernel<__bf16, false, 4, 2, 4>, ok0, "gemm_rows_256_kernel")) return rc;
             hipLaunchKernelGGL((gemm_rows_256_kernel<__bf16, false, 4, 2, 4>), dim3((unsigned)blocks2), dim3(kG2Threads), lds, stream, (const __bf16 *)A_, lda, n,
-                               (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, accumulate ? 1 : 0);
+                               (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, addend);
         }
         return check_launch("gemm_rows_256_kernel");
     }
@@ -367,10 +370,10 @@ int launch_gemm_rows_bf16(const void *A_, int lda, int64_t n, const void *B_, in
     if (blocks > 0x7fffffffLL) return set_error(MOT_EUNSUPPORTED, "gemm_rows_bf16: too many rows");
     if (out_bf16)
         hipLaunchKernelGGL((gemm_rows_bf16_kernel<true, WM>), dim3((unsigned)blocks), dim3(128 * WM), 0, stream, (const __bf16 *)A_, lda, n,
-                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, accumulate ? 1 : 0);
+                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, addend);
     else
         hipLaunchKernelGGL((gemm_rows_bf16_kernel<false, WM>), dim3((unsigned)blocks), dim3(128 * WM), 0, stream, (const __bf16 *)A_, lda, n,
-                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, accumulate ? 1 : 0);
+                           (const __bf16 *)B_, ldb, R, Nc, C, ldc, (const __bf16 *)bias, addend);
     return check_launch("gemm_rows_bf16_kernel");
 }
 

@@ -73,7 +73,7 @@ int launch_concat16(const MotEmbedMixDesc &d, const int32_t *tokens, const int64
                     void *out, float *row_rnorm, hipStream_t stream);
 int launch_wave_ids16(const MotEmbedMixDesc &d, uint16_t *ids16, hipStream_t stream);   // ids from the token->byte table, 16-bit, + parity outputs
 int launch_gemm_rows_bf16(const void *A, int lda, int64_t n, const void *B, int ldb, int R, int Nc, void *C, int ldc, bool out_bf16,
-                          const void *bias, hipStream_t stream, bool accumulate = false);
+                          const void *bias, hipStream_t stream, bool accumulate = false, const float *addend = nullptr);   // addend: fp32 [n][ldc] added before the store
 // the 256 x 256 LDS-DMA kernel of mot_gemm_bf16.hip with fp32 operands (B transposed: B[c][r])
 bool gemm_rows_f32_256_usable(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc);
 int launch_gemm_rows_f32_256(const float *A, int lda, int64_t n, const float *B, int ldb, int R, int Nc, float *C, int ldc, const float *bias, bool accumulate,

@@ -246,7 +246,10 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
     if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "char_swa: %d character rows x head_dim %d need %zu B of LDS (> 160 KiB)", d.char_rows, d.head_dim, lds);
     for (int64_t n0 = 0; n0 < N; n0 += slab) {
         const int64_t nn = N - n0 < slab ? N - n0 : slab;
-        float *out = (float *)d.out + n0 * d.dim;
+        // (io_dtype == MOT_BF16: the residuals go to the fp32 rows buffer, which the bf16 route leaves unused, and the last product adds
+        //  them and writes the bf16 result)
+        const bool out16 = d.io_dtype == MOT_BF16;
+        float *out = out16 ? xn : (float *)d.out + n0 * d.dim;
         // ---- queries: gather + RMSNorm, then the projection
         hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int32_t>, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.tokens + n0, nn,
                            (const float *)d.tok_table, d.tok_rows, d.dim, (const float *)d.attn_norm_w, eps, xn, d.status, kStatusTokenOor,
@@ -291,7 +294,10 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
             if ((rc = launch_embed_mix(r, stream))) return rc;
             accumulate = true;
         }
-        if (mm16) {
+        if (out16) {
+            if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, (__bf16 *)d.out + n0 * d.dim, d.dim, true, nullptr, stream, false,
+                                            accumulate ? out : nullptr))) return rc;
+        } else if (mm16) {
             if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, out, d.dim, false, nullptr, stream, accumulate))) return rc;
         } else if ((rc = launch_gemm_rows(yb, hdim, nn, (const float *)d.wo, hdim, hdim, d.dim, out, d.dim, true, stream, nullptr, accumulate))) return rc;
     }

@@ -842,7 +842,8 @@ def char_swa(tokens: torch.Tensor, char_ids: torch.Tensor, tok_table: torch.Tens
     d.norm_eps = float(norm_eps)
     d.attn_norm_w, d.char_norm_w, d.wq, d.wk, d.wv, d.wo = (capi.ptr(w) for w in ws_)
     d.lambda_tok, d.lambda_char = capi.ptr(lams[0]), capi.ptr(lams[1])
-    out = torch.empty((B, T, D), dtype=f32, device=dev)
+    d.io_dtype = capi.BF16 if (bf and mm_bf16) else capi.F32   # bf16 tables: the last product writes the bf16 result itself
+    out = torch.empty((B, T, D), dtype=torch.bfloat16 if d.io_dtype == capi.BF16 else f32, device=dev)
     d.out = capi.ptr(out)
     d.status = capi.ptr(capi.status_word(dev))
     if kv_cache is not None:
