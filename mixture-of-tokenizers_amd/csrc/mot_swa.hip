@@ -57,6 +57,42 @@ __global__ __launch_bounds__(kThreads) void rows_rmsnorm_w_kernel(const IdT *__r
     }
 }
 
+// h[n] += lambda_tok * E_tok[tok[n]] (+ lambda_char * mean_c E_char[cid[n][c]]) on a bf16 h (inference.py:264 / 267 with the attention
+// output a bf16 tensor, as `self.wo(...)` is in a bf16 cast): fp32 sum of the widened h and the fp32 rows, one rounding.  One wave per
+// token, 16-byte lanes; c_v = 0: the token term alone.
+__global__ __launch_bounds__(kThreads) void swa_residual_bf16_kernel(const int32_t *__restrict__ tokens, const int64_t *__restrict__ char_ids, int64_t n,
+                                                                     const float *__restrict__ tok_table, int64_t tok_rows, const float *__restrict__ char_table,
+                                                                     int64_t char_rows, int c_v, int dim, const float *__restrict__ lambda_tok,
+                                                                     const float *__restrict__ lambda_char, __bf16 *__restrict__ h, uint32_t *status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWaves + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (r >= n) return;
+    int64_t id = tokens[r];
+    if ((uint64_t)id >= (uint64_t)tok_rows) {
+        if (status && lane == 0) atomicOr(status, kStatusTokenOor);
+        id = 0;
+    }
+    int my = 0;   // lane c < c_v: the id of character c
+    if (lane < c_v) {
+        const int64_t c = char_ids[r * c_v + lane];
+        my = (int)c;
+        if ((uint64_t)c >= (uint64_t)char_rows) {
+            if (status) atomicOr(status, kStatusByteOor);
+            my = 0;
+        }
+    }
+    const float lt = lambda_tok ? *lambda_tok : 1.f, lc = (lambda_char ? *lambda_char : 1.f) / (float)(c_v > 0 ? c_v : 1);
+    const float *tp = tok_table + id * dim;
+    __bf16 *hp = h + r * dim;
+    for (int j = lane; j < (dim >> 2); j += 64) {
+        float4v x = Elem<__bf16>::load4(hp + 4 * j) + lt * *(const float4v *)(tp + 4 * j);
+        float4v m = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < c_v; ++c) m += *(const float4v *)(char_table + (int64_t)__builtin_amdgcn_readlane(my, c) * dim + 4 * j);
+        x += lc * m;
+        Elem<__bf16>::store4_nt(hp + 4 * j, x);
+    }
+}
+
 // The attention core.  Workgroup = (head h, tile of TT tokens); K_h and V_h of all character rows live in LDS for the whole
 // tile (132 x 64 x 2 floats = 68 KB at head_dim 64: two workgroups per CU); one wave per token.
 //   scores: lane = key (window * c_v <= 64 of them).  The query row's address is wave-uniform, so q arrives through the scalar
@@ -246,10 +282,10 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
     if (lds > 160 * 1024) return set_error(MOT_EUNSUPPORTED, "char_swa: %d character rows x head_dim %d need %zu B of LDS (> 160 KiB)", d.char_rows, d.head_dim, lds);
     for (int64_t n0 = 0; n0 < N; n0 += slab) {
         const int64_t nn = N - n0 < slab ? N - n0 : slab;
-        // (io_dtype == MOT_BF16: the residuals go to the fp32 rows buffer, which the bf16 route leaves unused, and the last product adds
-        //  them and writes the bf16 result)
+        // (io_dtype == MOT_BF16: the last product writes its result -- a bf16 tensor in the reference's bf16 cast -- in bf16 and the residuals
+        //  are added to it in place; adding them inside the product from an fp32 buffer cost it twice its time: 985 against 500 us)
         const bool out16 = d.io_dtype == MOT_BF16;
-        float *out = out16 ? xn : (float *)d.out + n0 * d.dim;
+        float *out = (float *)d.out + n0 * d.dim;
         // ---- queries: gather + RMSNorm, then the projection
         hipLaunchKernelGGL(rows_rmsnorm_w_kernel<int32_t>, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.tokens + n0, nn,
                            (const float *)d.tok_table, d.tok_rows, d.dim, (const float *)d.attn_norm_w, eps, xn, d.status, kStatusTokenOor,
@@ -274,6 +310,19 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
         if ((rc = check_launch("char_swa_kernel"))) return rc;
         // ---- residuals first (they overwrite `out`), then out += wo y
         bool accumulate = false;
+        if (out16) {
+            __bf16 *h16 = (__bf16 *)d.out + n0 * d.dim;
+            if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, h16, d.dim, true, nullptr, stream))) return rc;
+            if (d.version != MOT_SWA_NO_RESIDUAL) {
+                const bool two = d.version == MOT_SWA_TWO_RESIDUAL;
+                hipLaunchKernelGGL(swa_residual_bf16_kernel, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.tokens + n0,
+                                   d.char_ids + n0 * d.c_v, nn, (const float *)d.tok_table, d.tok_rows, (const float *)d.char_table, (int64_t)d.char_rows,
+                                   two ? d.c_v : 0, d.dim, two ? (const float *)d.lambda_tok : nullptr, two ? (const float *)d.lambda_char : nullptr, h16,
+                                   d.status);
+                if ((rc = check_launch("swa_residual_bf16_kernel"))) return rc;
+            }
+            continue;
+        }
         if (d.version != MOT_SWA_NO_RESIDUAL) {
             MotEmbedMixDesc r;
             memset(&r, 0, sizeof(r));
@@ -294,10 +343,7 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
             if ((rc = launch_embed_mix(r, stream))) return rc;
             accumulate = true;
         }
-        if (out16) {
-            if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, (__bf16 *)d.out + n0 * d.dim, d.dim, true, nullptr, stream, false,
-                                            accumulate ? out : nullptr))) return rc;
-        } else if (mm16) {
+        if (mm16) {
             if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, out, d.dim, false, nullptr, stream, accumulate))) return rc;
         } else if ((rc = launch_gemm_rows(yb, hdim, nn, (const float *)d.wo, hdim, hdim, d.dim, out, d.dim, true, stream, nullptr, accumulate))) return rc;
     }

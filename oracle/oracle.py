@@ -380,8 +380,8 @@ def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, 
     TokenMixByCharBMMBlock.forward up to `h` (260-267) -> TokenMixByCharBMM.forward (189-238, swa_transform 174-179).
     tokens (B, T), char_ids (B, T, c_v).  PARITY UNPINNED (see the section header).  numpy, small sizes only.
     round_token_products_bf16: the row operands of the two products over the tokens (the normalised token rows in front of wq,
-    the attention output in front of wo) and the projected queries, keys and values (bf16 tensors out of wq / wk / wv in the
-    reference's bf16 cast) are rounded to bf16 -- what the HIP path does with matmul_dtype = MOT_BF16."""
+    the attention output in front of wo), the projected queries, keys and values and the output of wo (bf16 tensors out of wq / wk /
+    wv / wo in the reference's bf16 cast) are rounded to bf16 -- what the HIP path does with matmul_dtype = MOT_BF16."""
     f = np.float64
     tok_table, char_table = np.asarray(tok_table, f), np.asarray(char_table, f)
     toks = tok_table[np.asarray(tokens)]                                   # (b, t, d)        line 323
@@ -421,6 +421,8 @@ def char_swa(tokens, char_ids, tok_table, char_table, attn_norm_w, char_norm_w, 
     if round_token_products_bf16:
         y = np.asarray(bf16_round(y), f)
     h = y @ np.asarray(wo, f).T                                             # 235
+    if round_token_products_bf16:
+        h = np.asarray(bf16_round(h), f)                                    # (self.wo(...) is a bf16 tensor before the residuals are added)
     if version == "one_residual":
         h = h + toks                                                        # 264
     elif version == "two_residual":

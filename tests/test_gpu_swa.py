@@ -156,12 +156,16 @@ def test_char_swa_bf16_tables(mot, matmul, T):
         # (an element of xn or y that sits on a bf16 rounding boundary can round the other way in fp32 than in float64 and moves an
         #  output by |w| 2^-8 |y|: a second step for a handful of outputs; an element of a key or value row that does moves every output
         #  whose token attends to that character a little: measured 99.72 % within one step and 1.04 steps at most at 660 tokens)
+        #  The output of wo is a bf16 tensor before the residuals are added (as in the reference's bf16 cast): where ITS rounding goes
+        #  the other way (a few elements in 10^4), the result is off by one bf16 step of that intermediate, whatever the size of the sum.
         emul = oracle(round_token_products_bf16=True)
+        attn = orc.char_swa(c16["toks"], c16["cid"], c16["Et"], c16["Ec"], c16["wa"], c16["wc"], c16["wq"], c16["wk"], c16["wv"], c16["wo"], n_heads=H,
+                            head_dim=hd, window=window, norm_eps=1e-5, version="no_residual", round_token_products_bf16=True)
         em = steps(emul)
-        assert (np.abs(got - emul) <= 1.5 * 2.0 ** -8 * np.maximum(np.abs(emul), np.sqrt((emul ** 2).mean()))).all() and (em <= 1).mean() > 0.995, \
-            (em.max(), (em <= 1).mean())
+        allowed = 1.5 * 2.0 ** -8 * np.maximum(np.abs(emul), np.sqrt((emul ** 2).mean())) + 2.0 ** -7 * np.abs(attn)
+        assert (np.abs(got - emul) <= allowed).all() and (em <= 1).mean() > 0.995, (em.max(), (em <= 1).mean())
         plain = oracle()   # without the two roundings: they move an output by ~2^-9 of the TYPICAL size of h, whatever its own size
-        assert (np.abs(got - plain) <= 3 * 2.0 ** -8 * np.maximum(np.abs(plain), np.sqrt((plain ** 2).mean()))).all()
+        assert (np.abs(got - plain) <= 3 * 2.0 ** -8 * np.maximum(np.abs(plain), np.sqrt((plain ** 2).mean())) + 2.0 ** -7 * np.abs(attn)).all()
 
 
 def test_char_swa_kv_cache_reuses_and_refreshes(mot):
