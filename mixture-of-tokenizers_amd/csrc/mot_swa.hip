@@ -313,7 +313,15 @@ int launch_char_swa(const MotCharSwaDesc &d, hipStream_t stream) {
         if (out16) {
             __bf16 *h16 = (__bf16 *)d.out + n0 * d.dim;
             if ((rc = launch_gemm_rows_bf16(a16, hdim, nn, wo16, hdim, hdim, d.dim, h16, d.dim, true, nullptr, stream))) return rc;
-            if (d.version != MOT_SWA_NO_RESIDUAL) {
+            MotEmbedMixDesc r;   // two_residual at the sizes of the LDS-table MEAN kernel: its read-modify-write form (the eight character rows of a
+            memset(&r, 0, sizeof(r));   // token come out of LDS there, out of L2 in the plain kernel below: 200 against 370 us at 65 536 x 2048)
+            r.struct_size = sizeof(r); r.dtype = MOT_F32; r.n_rows = 1; r.tokens_per_row = nn; r.tokens = d.tokens + n0;
+            r.tok_table = d.tok_table; r.tok_rows = d.tok_rows; r.tok_dim = d.dim; r.model_dim = d.dim; r.out = h16; r.status = d.status;
+            r.mode = MOT_MIX_MEAN; r.bpt = d.c_v; r.id_source = MOT_IDS_GIVEN; r.ids_a = d.char_ids + n0 * d.c_v;
+            r.byte_table = d.char_table; r.byte_rows = d.char_rows; r.byte_dim = d.dim; r.scale_tok = d.lambda_tok; r.scale_byte = d.lambda_char;
+            if (d.version == MOT_SWA_TWO_RESIDUAL && embed_mix_mean_takes_add16(r)) {
+                if ((rc = launch_embed_mix(r, stream, h16))) return rc;
+            } else if (d.version != MOT_SWA_NO_RESIDUAL) {
                 const bool two = d.version == MOT_SWA_TWO_RESIDUAL;
                 hipLaunchKernelGGL(swa_residual_bf16_kernel, dim3((unsigned)((nn + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, d.tokens + n0,
                                    d.char_ids + n0 * d.c_v, nn, (const float *)d.tok_table, d.tok_rows, (const float *)d.char_table, (int64_t)d.char_rows,

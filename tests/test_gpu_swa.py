@@ -168,6 +168,25 @@ def test_char_swa_bf16_tables(mot, matmul, T):
         assert (np.abs(got - plain) <= 3 * 2.0 ** -8 * np.maximum(np.abs(plain), np.sqrt((plain ** 2).mean())) + 2.0 ** -7 * np.abs(attn)).all()
 
 
+def test_char_swa_bf16_residual_paths_agree(mot):
+    """bf16 tables, two_residual: from 16 384 tokens on the residuals are added to the bf16 output of wo by the LDS-table MEAN kernel's
+    read-modify-write form, below that by the plain per-token kernel (what every other test of this file reaches).  One call over
+    2 x 8192 tokens against the same two batch rows in two calls: both add the same fp32 terms to the same bf16 values and round once,
+    in a different order of the character rows' sum -- equal but for roundings that sit on a boundary."""
+    B, T, c_v, d, H, hd, window = 2, 8192, 8, 256, 4, 64, 8
+    c = case(31, B, T, c_v, d, H, hd, 900, 132)
+    b16 = lambda a: dev(a).bfloat16()
+    t = {k: (b16(v) if v.dtype == np.float32 else dev(v)) for k, v in c.items()}
+    kw = dict(attn_norm_w=t["wa"], char_norm_w=t["wc"], wq=t["wq"], wk=t["wk"], wv=t["wv"], wo=t["wo"], n_heads=H, head_dim=hd, window=window,
+              version="two_residual", lambda_tok=torch.tensor([0.8], device=DEV).bfloat16(), lambda_char=torch.tensor([1.3], device=DEV).bfloat16())
+    whole = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], **kw)
+    rows = torch.cat([mot.functional.char_swa(t["toks"][i:i + 1], t["cid"][i:i + 1], t["Et"], t["Ec"], **kw) for i in range(B)])
+    mot.check_status()
+    assert whole.dtype == torch.bfloat16 and whole.shape == (B, T, d)
+    a, b = host(whole.float()).astype(np.float64), host(rows.float()).astype(np.float64)
+    assert (np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(b), 2.0 ** -6)).all() and (a == b).mean() > 0.999, (np.abs(a - b).max(), (a == b).mean())
+
+
 def test_char_swa_kv_cache_reuses_and_refreshes(mot):
     """`kv_cache`: the per-character key / value tables are built once and reused while char_table, char_norm_w, wk, wv are unchanged
     (same result bit for bit, with the cached tables); an in-place change of any of them rebuilds the tables."""
