@@ -145,50 +145,40 @@ __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__re
     const float scale = 1.0f / sqrtf((float)HD);                 // qk / self.head_dim ** .5, line 220
     const int g = lane / QUADS, dq = lane - g * QUADS;            // value pass: key group, element quad
     const int64_t t_lo = (int64_t)blockIdx.x * tile_tokens, t_hi = min(n_tok, t_lo + tile_tokens);
-    // the character id of this lane's key for token tl (-1: a padding key or no key): requested one token ahead of its use
-    auto key_id = [&](int64_t tl) -> int64_t {
-        const int64_t n = n0 + tl, tr = n % T, src_t = tr - (window - 1) + w;   // the window may not leave the token's batch row
-        return (tl < t_hi && lane < nkeys && src_t >= 0) ? char_ids[(n - tr + src_t) * c_v + c] : -1;
-    };
-    int64_t id_nx = key_id(t_lo + wave);
-    for (int64_t tl = t_lo + wave; tl < t_hi; tl += kSwaWaves) {
-        const int64_t idq = id_nx;
-        id_nx = key_id(tl + kSwaWaves);
-        const bool is_key = lane < nkeys, real = idq >= 0;       // not real: a zero vector of the padding (lines 175-176)
-        int id = 0;
-        if (real) {
-            id = (int)idq;
-            if ((uint64_t)idq >= (uint64_t)char_rows) { if (status) atomicOr(status, kStatusByteOor); id = 0; }
-        }
-        // ---- scores: q[tl, h, :] is addressed with scalars only
-        const float *qrow = q + tl * HDIM + h * HD;
-        const float *krow = lk + id * KS;
+    // scores of this lane's key against q[tl, h, :] (scalar addresses) from a key row in registers or in LDS
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    constexpr int KR = KV16 ? HD / 8 : HD / 4;                   // 16-byte pieces of a key row
+    auto dot_row = [&](int64_t tl, auto piece) -> float {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;           // four chains: a single one is 64 dependent fmas deep
-        if (KV16) {
+        if constexpr (KV16) {
             // (the query is a bf16 tensor too -- written so by its product -- and arrives as scalar pairs: v_dot2c_f32_bf16, one
             //  instruction per two dims where unpacking the key pairs for fp32 multiply-adds took four)
-            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             const uint32_t *q2 = (const uint32_t *)q + ((tl * HDIM + h * HD) >> 1);
 #pragma unroll
-            for (int d8 = 0; d8 < HD / 8; ++d8) {
-                const uint4 u = *(const uint4 *)(krow + 4 * d8);
+            for (int d8 = 0; d8 < KR; ++d8) {
+                const uint4 u = piece(d8);
                 s0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 0]), __builtin_bit_cast(bf16x2, u.x), s0, false);
                 s1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 1]), __builtin_bit_cast(bf16x2, u.y), s1, false);
                 s2 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 2]), __builtin_bit_cast(bf16x2, u.z), s2, false);
                 s3 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, q2[4 * d8 + 3]), __builtin_bit_cast(bf16x2, u.w), s3, false);
             }
         } else {
+            const float *qrow = q + tl * HDIM + h * HD;
 #pragma unroll
-            for (int d4 = 0; d4 < HD / 4; ++d4) {
-                const float4v kk = *(const float4v *)(krow + 4 * d4);
-                s0 += qrow[4 * d4 + 0] * kk.x;
-                s1 += qrow[4 * d4 + 1] * kk.y;
-                s2 += qrow[4 * d4 + 2] * kk.z;
-                s3 += qrow[4 * d4 + 3] * kk.w;
+            for (int d4 = 0; d4 < KR; ++d4) {
+                const uint4 u = piece(d4);
+                s0 += qrow[4 * d4 + 0] * __uint_as_float(u.x);
+                s1 += qrow[4 * d4 + 1] * __uint_as_float(u.y);
+                s2 += qrow[4 * d4 + 2] * __uint_as_float(u.z);
+                s3 += qrow[4 * d4 + 3] * __uint_as_float(u.w);
             }
         }
-        const float s = real ? ((s0 + s1) + (s2 + s3)) * scale : 0.f;
-        // ---- softmax over the nkeys keys (padding keys included, score 0)
+        return ((s0 + s1) + (s2 + s3)) * scale;
+    };
+    // softmax over the nkeys keys (padding keys included, score 0), then y = sum_j p_j v_j through the wave's (p, id) strip
+    auto finish = [&](int64_t tl, float s_real, bool real, int id) {
+        const bool is_key = lane < nkeys;
+        const float s = real ? s_real : 0.f;                     // not real: a zero vector of the padding (lines 175-176)
         const float m = wave_max(is_key ? s : -INFINITY);
         const float e = is_key ? expf(s - m) : 0.f;
         const float p = e / wave_sum(e);
@@ -196,7 +186,6 @@ __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__re
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // ---- y = sum_j p_j v_j
         float4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
         for (int j = g; j < 64; j += GROUPS) {
@@ -220,6 +209,68 @@ __global__ __launch_bounds__(kSwaThreads) void char_swa_kernel(const float *__re
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the strip is rewritten for the wave's next token
         __builtin_amdgcn_wave_barrier();
+    };
+    auto checked = [&](int64_t idq) -> int {
+        if ((uint64_t)idq >= (uint64_t)char_rows) { if (status) atomicOr(status, kStatusByteOor); return 0; }
+        return (int)idq;
+    };
+    if constexpr (HDL == 1) {
+        // head_dim 64: a wave takes CONSECUTIVE tokens and keeps its keys' rows in registers.  Lane (w, c) holds character c of the one
+        // token of the window whose position in its batch row is w modulo the window: from a query to the next, only the lanes whose
+        // slot the new token takes change their key -- c_v of 64 lanes re-read a row from LDS instead of all of them (the LDS reads of
+        // key and value rows are what bounds this kernel; the softmax and the value pass do not care which lane holds which key).
+        const int64_t per_wave = (tile_tokens + kSwaWaves - 1) / kSwaWaves;
+        const int64_t w_lo = min(t_hi, t_lo + wave * per_wave), w_hi = min(t_hi, w_lo + per_wave);
+        if (w_lo >= w_hi) return;                                // (no block barrier below)
+        const bool is_key = lane < nkeys;
+        uint4 kreg[KR];
+#pragma unroll
+        for (int d = 0; d < KR; ++d) kreg[d] = uint4{0u, 0u, 0u, 0u};
+        auto load_row = [&](int id) {
+#pragma unroll
+            for (int d = 0; d < KR; ++d) kreg[d] = *(const uint4 *)(lk + id * KS + 4 * d);
+        };
+        int id = 0;
+        bool real = false;
+        int64_t tr = (n0 + w_lo) % T;                            // position of the query in its batch row (wave-uniform)
+        {   // first query of the stretch: every lane finds the token of its slot
+            const int back = (int)(((tr % window) - w + window) % window);
+            const int64_t src = tr - back;
+            if (is_key && src >= 0) { real = true; id = checked(char_ids[(n0 + w_lo - back) * c_v + c]); load_row(id); }
+        }
+        // the characters of the NEXT query's own token, for the lanes of its slot: requested one query ahead
+        auto own_chars = [&](int64_t tl, int64_t tr_) -> int64_t {
+            return (tl < w_hi && is_key && w == (int)(tr_ % window)) ? char_ids[(n0 + tl) * c_v + c] : -1;
+        };
+        int64_t tr_nx = tr + 1 == T ? 0 : tr + 1;
+        int64_t id_nx = own_chars(w_lo + 1, tr_nx);
+        for (int64_t tl = w_lo; tl < w_hi; ++tl) {
+            const float s = dot_row(tl, [&](int d) { return kreg[d]; });
+            const int64_t idq = id_nx;
+            const int64_t tr_cur_nx = tr_nx;
+            tr_nx = tr_nx + 1 == T ? 0 : tr_nx + 1;
+            id_nx = own_chars(tl + 2, tr_nx);
+            finish(tl, s, real, id);
+            // the next query: its own token takes the slot of the oldest one; at the start of a batch row every other slot is padding
+            if (tr_cur_nx == 0 && w != 0) real = false;
+            if (idq >= 0) { real = true; id = checked(idq); load_row(id); }
+        }
+        return;
+    }
+    // the character id of this lane's key for token tl (-1: a padding key or no key): requested one token ahead of its use
+    auto key_id = [&](int64_t tl) -> int64_t {
+        const int64_t n = n0 + tl, tr = n % T, src_t = tr - (window - 1) + w;   // the window may not leave the token's batch row
+        return (tl < t_hi && lane < nkeys && src_t >= 0) ? char_ids[(n - tr + src_t) * c_v + c] : -1;
+    };
+    int64_t id_nx = key_id(t_lo + wave);
+    for (int64_t tl = t_lo + wave; tl < t_hi; tl += kSwaWaves) {
+        const int64_t idq = id_nx;
+        id_nx = key_id(tl + kSwaWaves);
+        const bool real = idq >= 0;
+        const int id = real ? checked(idq) : 0;
+        const float *krow = lk + id * KS;
+        const float s = dot_row(tl, [&](int d) { return *(const uint4 *)(krow + 4 * d); });
+        finish(tl, s, real, id);
     }
 }
 
