@@ -1,6 +1,7 @@
 // mot_swa.hip -- the Llama character mixer of BASELINE config 5 (gfx950): sliding-window token <- character attention
 // (inference/inference.py:146-224, TokenMixByCharBMM) on top of the two embedding gathers (323-327), with the residuals of
-// TokenMixByCharBMMBlock.forward (260-267).  fp32.
+// TokenMixByCharBMMBlock.forward (260-267).  fp32; with matmul_dtype = MOT_BF16 (bf16 tables and weights widened by the caller) the
+// outputs of wq / wk / wv / wo are kept as the bf16 tensors they are in a bf16 cast of the module and the result can leave in bf16.
 //
 //   xn = RMSNorm_a(E_tok[t])                 attention_norm, eps = norm_eps, learned weight           (lines 126-132, 261-267)
 //   cn = RMSNorm_c(E_char[c])                char_norm
