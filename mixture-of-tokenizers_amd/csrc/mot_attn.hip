@@ -43,6 +43,7 @@ struct AttnArgs {
     float *y;             // [T, HD]
     __bf16 *y16;          // optional: y once more in bf16 (the row operand of c_proj on the bf16 MFMA: no narrowing pass)
     const float *kt, *vt; // [rows, HD]: per byte-table row (ids != null) or per kv position (ids == null)
+    const __bf16 *kt16, *vt16;   // optional: the same two tables in bf16 (bf16 products: norm(k) and lambda v are bf16 tensors in the reference)
     const int64_t *ids;   // [T*bpt] byte ids or null
     int64_t rows;
     int64_t T;
@@ -194,8 +195,71 @@ __device__ __forceinline__ float quad_sum(float v) {
 }
 constexpr int kQuadPos = 4;         // positions whose cos / sin rows a wave stages in LDS
 constexpr int kQuadPosStride = 80;  // floats between them: 64 + 16, so that the quads of keys on different positions read different banks
+// The 32 dims of a head a lane of the lane-per-(key, quarter) kernels holds, as 16 pairs (d, d + 64) -- the pairs RoPE rotates -- n = 0..15:
+//   fp32 rows: d = 16 i + 4 j + e, n = 4 i + e  (16-byte pieces of 4 floats);   bf16 rows (L8): d = 32 i + 8 j + e, n = 8 i + e  (16-byte
+//   pieces of 8 bf16: the texture addresser takes a quad of lanes per cycle whatever the width of their pieces, so a row of half the
+//   bytes only costs half when it comes in half as many 16-byte pieces -- 8-byte pieces in the fp32 mapping were measured: no gain).
+template <bool L8>
+__device__ __forceinline__ void load16(const float *base, int j, float (&o)[16]) {   // o[n] = base[d(n)], base in LDS or global memory
+    if constexpr (L8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 a = *(const float4 *)(base + 32 * i + 8 * j), b = *(const float4 *)(base + 32 * i + 8 * j + 4);
+            o[8 * i] = a.x; o[8 * i + 1] = a.y; o[8 * i + 2] = a.z; o[8 * i + 3] = a.w; o[8 * i + 4] = b.x; o[8 * i + 5] = b.y; o[8 * i + 6] = b.z; o[8 * i + 7] = b.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 a = *(const float4 *)(base + 16 * i + 4 * j);
+            o[4 * i] = a.x; o[4 * i + 1] = a.y; o[4 * i + 2] = a.z; o[4 * i + 3] = a.w;
+        }
+    }
+}
+template <bool L8>
+__device__ __forceinline__ void store16(float *base, int j, const float (&o)[16]) {
+    if constexpr (L8) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *(float4 *)(base + 32 * i + 8 * j) = make_float4(o[8 * i], o[8 * i + 1], o[8 * i + 2], o[8 * i + 3]);
+            *(float4 *)(base + 32 * i + 8 * j + 4) = make_float4(o[8 * i + 4], o[8 * i + 5], o[8 * i + 6], o[8 * i + 7]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *(float4 *)(base + 16 * i + 4 * j) = make_float4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+    }
+}
+// one head slice of a table row (element offset off, a multiple of 128) into the two halves: fp32 rows 8 x 16 bytes, bf16 rows 4 x 16 bytes
+template <bool L8>
+__device__ __forceinline__ void load_row32(const void *table, int64_t off4, int j, float (&lo)[16], float (&hi)[16]) {
+    if constexpr (L8) {
+        const uint4 *p = (const uint4 *)table + (off4 >> 1) + j;
+        uint4 r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = p[4 * i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t a[4] = {r[i].x, r[i].y, r[i].z, r[i].w}, b[4] = {r[i + 2].x, r[i + 2].y, r[i + 2].z, r[i + 2].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                lo[8 * i + 2 * e] = __uint_as_float(a[e] << 16); lo[8 * i + 2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u);
+                hi[8 * i + 2 * e] = __uint_as_float(b[e] << 16); hi[8 * i + 2 * e + 1] = __uint_as_float(b[e] & 0xffff0000u);
+            }
+        }
+    } else {
+        const float4 *p = (const float4 *)table + off4 + j;
+        float4 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = p[4 * i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            lo[4 * i] = r[i].x; lo[4 * i + 1] = r[i].y; lo[4 * i + 2] = r[i].z; lo[4 * i + 3] = r[i].w;
+            hi[4 * i] = r[i + 4].x; hi[4 * i + 1] = r[i + 4].y; hi[4 * i + 2] = r[i + 4].z; hi[4 * i + 3] = r[i + 4].w;
+        }
+    }
+}
 __device__ __forceinline__ float lane_value(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
+template <bool KV16>   // KV16: keys and values from the bf16 tables
 __global__ __launch_bounds__(kThreads) void cross_attn_quad_kernel(const AttnArgs A) {
 #pragma clang fp contract(fast)
     __shared__ __attribute__((aligned(16))) float qs[kWaves][kHd];
@@ -256,35 +320,64 @@ __global__ __launch_bounds__(kThreads) void cross_attn_quad_kernel(const AttnArg
         }
     }
     const int off4 = (int)((row * HD + hk * kHd) >> 2);   // this key's head slice, in 16-byte units (the host checks rows * HD < 2^33)
-    const float4 *kp = (const float4 *)A.kt + off4 + j;
-    float4 k[8], ck[4], sk[4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) k[i] = kp[4 * i];
+    float klo[16], khi[16], ck[16], sk[16];
+    load_row32<KV16>(KV16 ? (const void *)A.kt16 : (const void *)A.kt, off4, j, klo, khi);
     __builtin_amdgcn_wave_barrier();   // (LDS operations of one wave complete in order: the rotated query and the cos / sin rows are there)
     if (staged) {
-        const float *cp = &cs[wv][0][dpos * kQuadPosStride + 4 * j], *sp = &cs[wv][1][dpos * kQuadPosStride + 4 * j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ck[i] = *(const float4 *)(cp + 16 * i); sk[i] = *(const float4 *)(sp + 16 * i); }
+        load16<KV16>(&cs[wv][0][dpos * kQuadPosStride], j, ck);
+        load16<KV16>(&cs[wv][1][dpos * kQuadPosStride], j, sk);
     } else {
-        const float4 *cp = (const float4 *)(A.cos_k + pos * 64) + j, *sp = (const float4 *)(A.sin_k + pos * 64) + j;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ck[i] = cp[4 * i]; sk[i] = sp[4 * i]; }
+        load16<KV16>(A.cos_k + pos * 64, j, ck);
+        load16<KV16>(A.sin_k + pos * 64, j, sk);
     }
     float s = 0.f;
+    {
+        float qa[16], qb[16];
+        load16<KV16>(&qs[wv][0], j, qa);
+        load16<KV16>(&qs[wv][64], j, qb);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 qa = *(const float4 *)&qs[wv][16 * i + 4 * j], qb = *(const float4 *)&qs[wv][64 + 16 * i + 4 * j];
-        const float4 a = k[i], b = k[i + 4], cc = ck[i], ss = sk[i];
-        s += qa.x * (a.x * cc.x + b.x * ss.x) + qb.x * (b.x * cc.x - a.x * ss.x);
-        s += qa.y * (a.y * cc.y + b.y * ss.y) + qb.y * (b.y * cc.y - a.y * ss.y);
-        s += qa.z * (a.z * cc.z + b.z * ss.z) + qb.z * (b.z * cc.z - a.z * ss.z);
-        s += qa.w * (a.w * cc.w + b.w * ss.w) + qb.w * (b.w * cc.w - a.w * ss.w);
+        for (int n = 0; n < 16; ++n) s += qa[n] * (klo[n] * ck[n] + khi[n] * sk[n]) + qb[n] * (khi[n] * ck[n] - klo[n] * sk[n]);
     }
     const float inv_sqrt_hd = 1.0f / sqrtf((float)kHd);
     const float sc = live ? quad_sum(s) * inv_sqrt_hd : -FLT_MAX;
     const float mx = wave_max(sc);
     float p = live ? expf(sc - mx) : 0.f;
     p /= wave_sum(j == 0 ? p : 0.f);
+    if constexpr (KV16) {
+        // y = sum_c p_c v_c: four groups of 16 lanes, group g the keys 4 cc + g, a lane 8 dims (one 16-byte piece of the bf16 row)
+        const int g = lane >> 4, m = lane & 15;
+        const uint4 *vt8 = (const uint4 *)A.vt16 + m;
+        const int off8 = off4 >> 1;
+        float y[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        auto four_keys = [&](int cc) {
+            const int src = 4 * (4 * cc + g);   // a lane of that key's quad
+            const float pc = __shfl(p, src, 64);
+            const uint4 r = vt8[__shfl(off8, src, 64)];
+            const uint32_t u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { y[2 * e] += pc * __uint_as_float(u[e] << 16); y[2 * e + 1] += pc * __uint_as_float(u[e] & 0xffff0000u); }
+        };
+        if (A.bpt > 12) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) four_keys(cc);
+        } else {
+            for (int cc = 0; 4 * cc < A.bpt; ++cc) four_keys(cc);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { y[e] += __shfl_xor(y[e], 16, 64); y[e] += __shfl_xor(y[e], 32, 64); }
+        const int64_t o = t * HD + h * kHd + 8 * m;
+        if (g == 0) {
+            *(float4 *)(A.y + o) = make_float4(y[0], y[1], y[2], y[3]);
+            *(float4 *)(A.y + o + 4) = make_float4(y[4], y[5], y[6], y[7]);
+        } else if (g == 1 && A.y16) {
+            typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+            bf16x8 b;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b[e] = (__bf16)y[e];
+            *(bf16x8 *)(A.y16 + o) = b;
+        }
+        return;
+    }
     // y = sum_c p_c v_c: lanes 0..31 take the even keys, 32..63 the odd ones, 4 dims each
     const int g = lane >> 5, m = lane & 31;
     const float4 *vt4 = (const float4 *)A.vt + m;
@@ -326,14 +419,16 @@ static int launch_attention(const AttnArgs &A, hipStream_t stream) {
     const int64_t waves = A.T * A.H;
     const dim3 grid((unsigned)((waves + kWaves - 1) / kWaves));
     if (quad_form(A.bpt, A.rows, A.H * kHd, A.kt, A.vt, A.cos_k, A.sin_k) && !(((uintptr_t)A.y | (uintptr_t)A.y16) & 15))
-        hipLaunchKernelGGL(cross_attn_quad_kernel, grid, dim3(kThreads), 0, stream, A);
-    else hipLaunchKernelGGL(cross_attn_kernel, grid, dim3(kThreads), 0, stream, A);
+    {
+        if (A.kt16 && A.vt16) hipLaunchKernelGGL(cross_attn_quad_kernel<true>, grid, dim3(kThreads), 0, stream, A);
+        else hipLaunchKernelGGL(cross_attn_quad_kernel<false>, grid, dim3(kThreads), 0, stream, A);
+    } else hipLaunchKernelGGL(cross_attn_kernel, grid, dim3(kThreads), 0, stream, A);
     return check_launch("cross_attn_kernel");
 }
 
 // ------------------------------------------------------------------------------------------ host
 // workspace, in floats: [q: T*HD][y: T*HD][kt: R*HD][vt: R*HD][xkv: R*D (dual: R = T*bpt)][xq: D > HD ? T*D : 0]
-struct AttnLayout { size_t q, y, kt, vt, xkv, xq, a16, w16, part, part_n, total; int64_t R; };
+struct AttnLayout { size_t q, y, kt, vt, xkv, xq, a16, w16, part, part_n, kt16, vt16, total; int64_t R; };
 // matmul_dtype == MOT_BF16: the two products over the tokens (q = W_q xq, out = c_proj y) run on the bf16 MFMA
 // (launch_gemm_rows_bf16, fp32 accumulation and fp32 results): their row operands are rounded to bf16 first -- the reference's own
 // rounding points in the production cast (xq is a bf16 tensor out of norm(), y one out of the attention, train_gpt.py:277, 292-293;
@@ -364,6 +459,10 @@ static AttnLayout attn_layout(const MotCrossAttnDesc &d) {
     L.w16 = take(mm16(d) ? ((dual ? 2 : 1) * HD * D + 1) / 2 : 0);
     L.part_n = gemm_rows_sliced_floats(L.R, (int)D, (int)HD);   // the key / value projections of the few byte-table rows, cut along dim
     L.part = take(L.part_n);
+    // bf16 products, one id tensor: the two tables once more in bf16 for the attention kernel (per kv position they would cost a pass
+    // over 2 x T*bpt x HD to make, what reading them in bf16 saves)
+    const size_t t16 = mm16(d) && !dual ? ((size_t)L.R * HD + 1) / 2 : 0;
+    L.kt16 = take(t16); L.vt16 = take(t16);
     L.total = o;
     return L;
 }
@@ -441,6 +540,12 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
     A.q = q; A.y = y; A.kt = kt; A.vt = vt; A.ids = dual ? nullptr : d.ids_a; A.rows = L.R; A.T = T; A.bpt = d.bpt; A.H = H;
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
     A.y16 = mm16(d) ? (__bf16 *)(ws + L.a16) : nullptr;   // (the row operand of q has been consumed: stream order)
+    A.kt16 = A.vt16 = nullptr;
+    if (mm16(d) && !dual && d.bpt <= 16) {
+        if ((rc = launch_narrow(kt, L.R * HD, ws + L.kt16, stream))) return rc;
+        if ((rc = launch_narrow(vt, L.R * HD, ws + L.vt16, stream))) return rc;
+        A.kt16 = (const __bf16 *)(ws + L.kt16); A.vt16 = (const __bf16 *)(ws + L.vt16);
+    }
     if ((rc = launch_attention(A, stream))) return rc;
     // 4. out = c_proj y                   (line 293): out[t][c] = sum_r y[t][r] * proj_w[c][r]
     if (mm16(d)) {
@@ -471,6 +576,7 @@ int launch_cross_attn(const MotCrossAttnDesc &d, hipStream_t stream) {
 struct AttnBwdArgs {
     const float *q_pre, *dy;   // [T, HD]
     const float *kn, *vpre;    // [rows, HD]
+    const __bf16 *kn16, *vl16; // optional: norm(k) and lambda v in bf16, as the forward read them
     const float *lambda;
     const int64_t *ids;
     int64_t rows, T;
@@ -625,6 +731,7 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_kernel(const AttnBwdA
 // The same for bpt <= 16 in the forward's lane-per-(key, quarter) form (cross_attn_quad_kernel): the keys are loaded and rotated
 // once and stay in registers for the query gradient, whose sum over the keys runs over the lanes of a 16-lane row by two DPP
 // rotates and over the four rows through 2 KB of LDS.
+template <bool KV16>   // KV16: norm(k) and lambda v from their bf16 copies (kn16, vl16), in the forward's bf16-row lane layout
 __global__ __launch_bounds__(kThreads) void cross_attn_bwd_quad_kernel(const AttnBwdArgs A) {
 #pragma clang fp contract(fast)
     __shared__ __attribute__((aligned(16))) float qs[kWaves][kHd], dys[kWaves][kHd], red[kWaves][4][kHd];
@@ -678,8 +785,42 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_quad_kernel(const Att
         if ((uint64_t)row >= (uint64_t)A.rows) row = 0;   // flagged by the forward
     }
     const int off4 = (int)((row * HD + hk * kHd) >> 2);
-    const float4 *kp = (const float4 *)A.kn + off4 + j, *vp = (const float4 *)A.vpre + off4 + j;
     float4 k[8], v[8];
+    float krl[16], krh[16];   // KV16: the rotated key, dims d(n) and d(n) + 64
+    float s = 0.f, dpv = 0.f;
+    if constexpr (KV16) {
+        float vlo[16], vhi[16], ck[16], sk[16];
+        load_row32<true>(A.kn16, off4, j, krl, krh);
+        load_row32<true>(A.vl16, off4, j, vlo, vhi);
+        __builtin_amdgcn_wave_barrier();
+        if (staged) {
+            load16<true>(&cs[wv][0][dpos * kQuadPosStride], j, ck);
+            load16<true>(&cs[wv][1][dpos * kQuadPosStride], j, sk);
+        } else {
+            load16<true>(A.cos_k + pos * 64, j, ck);
+            load16<true>(A.sin_k + pos * 64, j, sk);
+        }
+        {
+            float qa[16], qb[16];
+            load16<true>(&qs[wv][0], j, qa);
+            load16<true>(&qs[wv][64], j, qb);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) {
+                const float x = krl[n], y = krh[n];
+                krl[n] = x * ck[n] + y * sk[n];
+                krh[n] = y * ck[n] - x * sk[n];
+                s += qa[n] * krl[n] + qb[n] * krh[n];
+            }
+        }
+        {
+            float da[16], db[16];
+            load16<true>(&dys[wv][0], j, da);
+            load16<true>(&dys[wv][64], j, db);
+#pragma unroll
+            for (int n = 0; n < 16; ++n) dpv += da[n] * vlo[n] + db[n] * vhi[n];
+        }
+    } else {
+    const float4 *kp = (const float4 *)A.kn + off4 + j, *vp = (const float4 *)A.vpre + off4 + j;
 #pragma unroll
     for (int i = 0; i < 8; ++i) k[i] = kp[4 * i];
 #pragma unroll
@@ -688,7 +829,6 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_quad_kernel(const Att
     const float *cl = &cs[wv][0][dpos * kQuadPosStride + 4 * j], *sl = &cs[wv][1][dpos * kQuadPosStride + 4 * j];
     const float4 *cg = (const float4 *)(A.cos_k + pos * 64) + j, *sg = (const float4 *)(A.sin_k + pos * 64) + j;
     // scores (the keys rotated in place) and dp_c = dy . v_c
-    float s = 0.f, dpv = 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float4 qa = *(const float4 *)&qs[wv][16 * i + 4 * j], qb = *(const float4 *)&qs[wv][64 + 16 * i + 4 * j];
@@ -709,11 +849,12 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_quad_kernel(const Att
         dpv += da.w * v[i].w + db.w * v[i + 4].w;
 
     }
+    }
     const float sc = live ? quad_sum(s) * inv_sqrt : -FLT_MAX;
     const float mx = wave_max(sc);
     float p = live ? expf(sc - mx) : 0.f;
     p /= wave_sum(j == 0 ? p : 0.f);
-    const float dp = lam * quad_sum(dpv);
+    const float dp = (KV16 ? 1.f : lam) * quad_sum(dpv);   // (vl16 is lambda v already)
     const float dot = wave_sum(j == 0 ? p * dp : 0.f);
     const float ds = p * (dp - dot) * inv_sqrt;
     if (live && j == 0) {
@@ -721,6 +862,18 @@ __global__ __launch_bounds__(kThreads) void cross_attn_bwd_quad_kernel(const Att
         A.dsw[th * A.bpt + c] = ds;
     }
     // dq_r = sum_c ds_c k_r: over the four keys of a 16-lane row by DPP, over the four rows through LDS
+    if constexpr (KV16) {
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            krl[n] *= ds; krh[n] *= ds;
+            krl[n] += dpp_move<kDppRowRor4, 0xf>(0.f, krl[n]); krh[n] += dpp_move<kDppRowRor4, 0xf>(0.f, krh[n]);
+            krl[n] += dpp_move<kDppRowRor8, 0xf>(0.f, krl[n]); krh[n] += dpp_move<kDppRowRor8, 0xf>(0.f, krh[n]);
+        }
+        if ((lane & 12) == 0) {
+            store16<true>(&red[wv][lane >> 4][0], j, krl);
+            store16<true>(&red[wv][lane >> 4][64], j, krh);
+        }
+    } else
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         float4 x = make_float4(ds * k[i].x, ds * k[i].y, ds * k[i].z, ds * k[i].w);
@@ -1006,7 +1159,7 @@ __global__ __launch_bounds__(kThreads) void iota_i32_kernel(int32_t *__restrict_
 
 // workspace of the backward, in floats
 struct AttnBwdLayout {
-    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, ids32b, emb, emb_bytes, b0, b1, w16, x16, dq16, part, part_n, total;
+    size_t q, y, kpre, vpre, kn, vl, dy, dq, pw, dsw, qrot, grp, dkn_tab, dvl_tab, dkv, xkv, dxkv, xq, dxq, ids32, ids32b, emb, emb_bytes, b0, b1, w16, x16, dq16, part, part_n, kn16, vl16, total;
 };
 static void noop_bwd_desc(MotEmbedMixDesc &e, const void *tokens, int64_t n, const void *table, int64_t rows, int dim, int norm, float eps, uint32_t *status) {
     memset(&e, 0, sizeof(e));
@@ -1046,6 +1199,8 @@ static AttnBwdLayout attn_bwd_layout(const MotCrossAttnDesc &d) {
     const size_t pa = gemm_rows_sliced_floats((int64_t)R, (int)D, (int)HD), pb = gemm_rows_sliced_floats((int64_t)R, (int)(2 * HD), (int)D);
     L.part_n = pa > pb ? pa : pb;
     L.part = take(L.part_n);
+    const size_t t16 = mm16(d) && !dual ? (R * HD + 1) / 2 : 0;   // norm(k), lambda v in bf16 (as in the forward)
+    L.kn16 = take(t16); L.vl16 = take(t16);
     L.total = o;
     return L;
 }
@@ -1120,6 +1275,12 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     A.q = q; A.y = y; A.kt = kn; A.vt = vl; A.ids = dual ? nullptr : d.ids_a; A.rows = R; A.T = T; A.bpt = d.bpt; A.H = H;
     A.layout = d.head_layout; A.cos_q = d.cos_q; A.sin_q = d.sin_q; A.cos_k = d.cos_k; A.sin_k = d.sin_k; A.eps = eps; A.status = d.status;
     A.y16 = nullptr;
+    A.kt16 = A.vt16 = nullptr;
+    if (mm16(d) && !dual && d.bpt <= 16) {   // norm(k) and lambda v in bf16, as the forward's attention read them
+        if ((rc = launch_narrow(kn, R * HD, ws + L.kn16, stream))) return rc;
+        if ((rc = launch_narrow(vl, R * HD, ws + L.vl16, stream))) return rc;
+        A.kt16 = (const __bf16 *)(ws + L.kn16); A.vt16 = (const __bf16 *)(ws + L.vl16);
+    }
     const int64_t waves = T * H;
     if (!d.saved_qy && (rc = launch_attention(A, stream))) return rc;
     // ---- c_proj:  dW_p += g^T y;  dy = g W_p   (proj_w [D, HD] is the k-major operand of g[T, D] -> dy[T, HD])
@@ -1146,9 +1307,11 @@ int launch_cross_attn_bwd(const MotCrossAttnDesc &d, const MotCrossAttnGrads &gr
     B.layout = d.head_layout; B.cos_q = d.cos_q; B.sin_q = d.sin_q; B.cos_k = d.cos_k; B.sin_k = d.sin_k; B.eps = eps;
     B.dq = dq; B.pw = pw; B.dsw = dsw; B.qrot = qrot;
     B.dq16 = mm16(d) ? (__bf16 *)(ws + L.dq16) : nullptr;
-    if (quad_form(B.bpt, R, HD, B.kn, B.vpre, B.cos_k, B.sin_k))
-        hipLaunchKernelGGL(cross_attn_bwd_quad_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
-    else hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
+    B.kn16 = A.kt16; B.vl16 = A.vt16;
+    if (quad_form(B.bpt, R, HD, B.kn, B.vpre, B.cos_k, B.sin_k)) {
+        if (B.kn16 && B.vl16) hipLaunchKernelGGL(cross_attn_bwd_quad_kernel<true>, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
+        else hipLaunchKernelGGL(cross_attn_bwd_quad_kernel<false>, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
+    } else hipLaunchKernelGGL(cross_attn_bwd_kernel, dim3((unsigned)((waves + kWaves - 1) / kWaves)), dim3(kThreads), 0, stream, B);
     if ((rc = check_launch("cross_attn_bwd_kernel"))) return rc;
     // ---- per byte-table row: the sums over the kv positions of every byte id, from the grouped positions
     {

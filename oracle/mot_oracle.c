@@ -271,6 +271,10 @@ void oracle_set_round_segments_bf16(int on) { g_round_seg_bf16 = on; }
  * (model.py:51-58) keeps the head's dtype.  Only the float64 instantiation can tell the two apart. */
 static int g_rotary_f32_cast = 1;
 void oracle_set_rotary_f32_cast(int on) { g_rotary_f32_cast = on; }
+/* Cross-attention with bf16 tables: norm(k) and lambda * v are bf16 TENSORS in the reference's bf16 cast (train_gpt.py:278, 280);
+ * on = round them to bf16 where they are formed (the keys before their rotation), as the HIP path keeps them with bf16 products. */
+static int g_round_kv_bf16 = 0;
+void oracle_set_round_kv_bf16(int on) { g_round_kv_bf16 = on; }
 static double bf16_rne(double x) {
     float f = (float)x; uint32_t u; memcpy(&u, &f, 4);
     u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;

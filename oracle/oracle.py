@@ -61,6 +61,12 @@ def set_round_segments_bf16(on: bool) -> None:
     lib().oracle_set_round_segments_bf16(C.c_int(int(on)))
 
 
+def set_round_kv_bf16(on: bool) -> None:
+    """cross_attn (forward): round norm(k) and lambda * v to bf16 where they are formed -- bf16 tensors in the reference's bf16 cast
+    (train_gpt.py:278, 280) and what the HIP path keeps with matmul_dtype = MOT_BF16 (one id tensor, at most 16 keys per token)."""
+    lib().oracle_set_round_kv_bf16(C.c_int(int(on)))
+
+
 def set_rotary_f32_cast(on: bool) -> None:
     """Rotary casts each head to float32 before rotating (train_gpt.py:202, the default) or keeps its dtype
     (mathblations/model.py:51-58); a difference in the float64 functions only."""
