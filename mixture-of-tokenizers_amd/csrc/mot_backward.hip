@@ -1887,7 +1887,8 @@ int launch_gemm_tn(const float *A_, int lda, int M, const float *B_, int ldb, in
 // the fp32 MFMA peak; this loop reaches ~75 %.
 template <bool BT>
 __device__ __forceinline__ void gemm_rows_body(const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb,
-                                               int R, int Nc, float *__restrict__ C, int ldc, const float *__restrict__ bias, int accumulate) {
+                                               int R, int Nc, float *__restrict__ C, int ldc, const float *__restrict__ bias, int accumulate,
+                                               bool plain_order = false) {
     // transposed operands sit in LDS with a row stride of 132 floats: the 4 lanes that share a source row (coalesced 64-byte
     // reads) then write to banks 16 apart, two lanes per bank -- the minimum for 64 dword writes
     constexpr int LDA = 132, LDB = BT ? 132 : 128;
@@ -1897,7 +1898,9 @@ __device__ __forceinline__ void gemm_rows_body(const float *__restrict__ A_, int
     // back to back, so the panel of A is fetched into that XCD's L2 once instead of once per column block
     const int64_t gx = (n + 127) / 128;
     const int gy = (Nc + 127) / 128;
-    const int64_t bid = blockIdx.x, seq = bid >> 3, panel = (seq / gy) * 8 + (bid & 7);
+    // (plain_order: gx * gy blocks, no padding -- the sliced few-row launches, where the padded panels were most of the workgroups and
+    //  their dispatch most of the time: 132 rows = 2 panels padded to 8, 2816 workgroups of which 704 work, 100 us)
+    const int64_t bid = blockIdx.x, seq = plain_order ? bid : bid >> 3, panel = plain_order ? bid / gy : (seq / gy) * 8 + (bid & 7);
     if (panel >= gx) return;   // the grid is padded to whole groups of 8 panels
     const int64_t j0 = panel * 128;
     const int k0 = (int)(seq % gy) * 128;
@@ -2017,13 +2020,14 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(3, 4))
     const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb, int R, int Nc, float *__restrict__ C, int ldc,
     const float *__restrict__ bias, int accumulate, int slice, int64_t part_stride) {
     const int r0 = blockIdx.y * slice;
-    gemm_rows_body<true>(A_ + r0, lda, n, B_ + r0, ldb, slice ? min(slice, R - r0) : R, Nc, C + blockIdx.y * part_stride, ldc, bias, accumulate);
+    gemm_rows_body<true>(A_ + r0, lda, n, B_ + r0, ldb, slice ? min(slice, R - r0) : R, Nc, C + blockIdx.y * part_stride, ldc, bias, accumulate, slice != 0);
 }
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 4))) void gemm_rows_kernel(
     const float *__restrict__ A_, int lda, int64_t n, const float *__restrict__ B_, int ldb, int R, int Nc, float *__restrict__ C, int ldc,
     const float *__restrict__ bias, int accumulate, int slice, int64_t part_stride) {
     const int r0 = blockIdx.y * slice;
-    gemm_rows_body<false>(A_ + r0, lda, n, B_ + (int64_t)r0 * ldb, ldb, slice ? min(slice, R - r0) : R, Nc, C + blockIdx.y * part_stride, ldc, bias, accumulate);
+    gemm_rows_body<false>(A_ + r0, lda, n, B_ + (int64_t)r0 * ldb, ldb, slice ? min(slice, R - r0) : R, Nc, C + blockIdx.y * part_stride, ldc, bias, accumulate,
+                          slice != 0);
 }
 // C[i] = part[0][i] + part[1][i] + ... in that order (C rows ldc apart, the partial blocks dense [n][Nc])
 __global__ __launch_bounds__(kThreads) void gemm_rows_sum_slices_kernel(const float *__restrict__ part, int slices, int64_t n, int Nc, float *__restrict__ C, int ldc) {
@@ -2082,7 +2086,7 @@ int launch_gemm_rows_sliced(const float *A_, int lda, int64_t n, const float *B_
     int len = 0;
     const int slices = n > 0 && Nc > 0 ? gemm_rows_slices(n, R, Nc, &len) : 1;
     if (slices < 2 || !part || part_floats < (size_t)slices * n * Nc) return launch_gemm_rows(A_, lda, n, B_, ldb, R, Nc, C, ldc, b_transposed, stream);
-    const int64_t blocks = ((n + 127) / 128 + 7) / 8 * 8 * ((Nc + 127) / 128);
+    const int64_t blocks = ((n + 127) / 128) * ((Nc + 127) / 128);   // (plain block order in the sliced launches: no padded panels)
     const dim3 grid((unsigned)blocks, (unsigned)slices);
     if (b_transposed)
         hipLaunchKernelGGL(gemm_rows_bt_kernel, grid, dim3(kThreads), 0, stream, A_, lda, n, B_, ldb, R, Nc, part, Nc, (const float *)nullptr, 0, len, n * Nc);
