@@ -40,7 +40,7 @@ def main():
                 if r["Counter_Name"] == kind:
                     agg[r["Kernel_Name"][:100]].append(float(r["Counter_Value"]))
             pmc[kind] = {k: {"launches": len(v), "mean_KB": sum(v) / len(v), "min_KB": min(v), "max_KB": max(v)}
-                         for k, v in agg.items() if k.startswith("void mot::")}
+                         for k, v in agg.items() if k.startswith(("void mot::", "mot::", "_ZN3mot"))}   # (kernels with __bf16 template arguments come out mangled)
         (HERE / f"{tag}_pmc.json").write_text(json.dumps(pmc, indent=1) + "\n")
         kern = max(pmc["WRITE_SIZE"], key=lambda k: pmc["WRITE_SIZE"][k]["mean_KB"])
         fetch, write = pmc["FETCH_SIZE"][kern]["mean_KB"], pmc["WRITE_SIZE"][kern]["mean_KB"]
