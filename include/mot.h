@@ -337,8 +337,9 @@ typedef struct MotCrossAttnDesc {
     /* MOT_F32 (0) or MOT_BF16: where the products over the tokens run (q = W_q xq, out = c_proj y; backward: dW_p, dy, dW_q, dxq).
      * MOT_BF16 = the bf16 MFMA with fp32 accumulation: their row operands (xq, y, grad_out, dq) are rounded to bf16 first and the
      * weights are taken as bf16 -- the values those operands have in the reference's production cast (CastedLinear and
-     * `self.q_w.type_as(x)`, train_gpt.py:185-186, 277-278; x bf16 since 1124-1126); tables, attention and every result stay
-     * fp32.  Needs dim % 8 == 0.  Workspace sizes depend on it. */
+     * `self.q_w.type_as(x)`, train_gpt.py:185-186, 277-278; x bf16 since 1124-1126).  With one id tensor and bpt <= 16 the attention
+     * kernels also read norm(k) and lambda * v from bf16 copies of the two per-row tables (bf16 tensors in that cast, lines 278, 280);
+     * the attention arithmetic, the tables themselves and every gradient stay fp32.  Needs dim % 8 == 0.  Workspace sizes depend on it. */
     int32_t matmul_dtype;
     /* MOT_F32 (0) or, with matmul_dtype == MOT_BF16, MOT_BF16: the element type of `out` (forward) and of MotCrossAttnGrads.grad_out
      * (backward).  bf16 is what the reference's module returns and receives in the production cast; the last product then writes
@@ -419,7 +420,8 @@ typedef struct MotCharSwaDesc {
     size_t workspace_bytes;
     /* MOT_F32 (0) or MOT_BF16: where the two products over the tokens run (xq = wq xn, h = wo y).  MOT_BF16 = the bf16 MFMA with
      * fp32 accumulation, xn and y rounded to bf16 first and the weights taken as bf16 (for callers whose tables and weights
-     * hold bf16 values; the reference script runs in float32); needs dim % 8 == 0 and (heads * head_dim) % 8 == 0. */
+     * hold bf16 values; the reference script runs in float32), and the projected queries, keys and values kept as the bf16 tensors
+     * they are in a bf16 cast of the module (fp32 softmax and sums); needs dim % 8 == 0 and (heads * head_dim) % 8 == 0. */
     int32_t matmul_dtype;
     /* 1 = `kv_tables` already holds this call's per-character key / value tables (skip building them) */
     int32_t kv_tables_ready;
