@@ -187,6 +187,38 @@ def test_char_swa_bf16_residual_paths_agree(mot):
     assert (np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(b), 2.0 ** -6)).all() and (a == b).mean() > 0.999, (np.abs(a - b).max(), (a == b).mean())
 
 
+@pytest.mark.parametrize("tables", ["fp32", "bf16"])
+def test_char_swa_is_capturable_in_a_hip_graph(mot, tables):
+    """mot_char_swa_fwd enqueues everything on the caller's stream without a sync -- the sliced few-row products and their ordered sums,
+    the bf16 routes' narrowing / widening passes, the attention core, the residual kernels: capture, change the inputs in place,
+    replay, compare with an eager call on the changed inputs (bit for bit: no atomics on this path)."""
+    B, T, c_v, d, H, hd, window = 2, 90, 8, 256, 4, 64, 8
+    c = case(41, B, T, c_v, d, H, hd, 600, 132)
+    cast = (lambda a: dev(a).bfloat16()) if tables == "bf16" else dev
+    t = {k: (cast(v) if v.dtype == np.float32 else dev(v)) for k, v in c.items()}
+    lam = lambda x: torch.tensor([x], device=DEV, dtype=torch.bfloat16 if tables == "bf16" else torch.float32)
+    kw = dict(attn_norm_w=t["wa"], char_norm_w=t["wc"], wq=t["wq"], wk=t["wk"], wv=t["wv"], wo=t["wo"], n_heads=H, head_dim=hd, window=window,
+              version="two_residual", lambda_tok=lam(0.8), lambda_char=lam(1.3), matmul=None if tables == "bf16" else "bf16")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s), torch.no_grad():
+        mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], **kw)      # warm-up: allocates the workspace
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph, stream=s):
+        out = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], **kw)
+    rs = np.random.RandomState(42)
+    t["toks"].copy_(dev(rs.randint(0, 600, (B, T)).astype(np.int32)))
+    t["cid"].copy_(dev(rs.randint(0, 132, (B, T, c_v)).astype(np.int64)))
+    t["wk"].mul_(1.25)
+    graph.replay()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], **kw)
+    mot.check_status()
+    assert out.dtype == (torch.bfloat16 if tables == "bf16" else torch.float32) and torch.equal(out, ref)
+
+
 def test_char_swa_kv_cache_reuses_and_refreshes(mot):
     """`kv_cache`: the per-character key / value tables are built once and reused while char_table, char_norm_w, wk, wv are unchanged
     (same result bit for bit, with the cached tables); an in-place change of any of them rebuilds the tables."""
