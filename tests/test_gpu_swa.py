@@ -139,7 +139,7 @@ def test_char_swa_bf16_tables(mot, matmul, T):
     B, c_v, d, H, hd, window = 2, 8, 256, 4, 64, 8
     c = case(21, B, T, c_v, d, H, hd, 700, 132)
     c16 = {k: (orc.bf16_round(v) if v.dtype == np.float32 else v) for k, v in c.items()}
-    lt, lc = float(orc.bf16_round(np.float32(0.8))), float(orc.bf16_round(np.float32(1.3)))
+    lt, lc = (float(np.asarray(orc.bf16_round(np.float32(v))).reshape(-1)[0]) for v in (0.8, 1.3))
     oracle = lambda **kw: orc.char_swa(c16["toks"], c16["cid"], c16["Et"], c16["Ec"], c16["wa"], c16["wc"], c16["wq"], c16["wk"], c16["wv"], c16["wo"],
                                        n_heads=H, head_dim=hd, window=window, norm_eps=1e-5, version="two_residual", lambda_tok=lt, lambda_char=lc, **kw)
     b16 = lambda a: dev(a).bfloat16()
