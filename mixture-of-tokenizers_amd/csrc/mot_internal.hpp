@@ -82,6 +82,7 @@ int launch_gemm_rows_f32_256(const float *A, int lda, int64_t n, const float *B,
 // C[m][k] += sum_n A[n][m] * B[n][k]  (bf16 row-major operands, fp32 atomics into C; mot_backward.hip); lda / ldb / M / Kc multiples of 8
 int launch_gemm_tn_bf16(const __bf16 *A, int lda, int M, const __bf16 *B, int ldb, int Kc, int64_t rows, float *C, int ldc, hipStream_t stream);
 int launch_narrow(const float *src, int64_t n, void *dst_bf16, hipStream_t stream);                                  // dst[i] = bf16(src[i])
+int launch_transpose_f32(const float *src, int rows, int cols, float *dst, hipStream_t stream);                        // dst[c][r] = src[r][c]
 int launch_narrow_transpose(const float *src, int rows, int cols, void *dst_bf16, hipStream_t stream);               // dst[c][r] = bf16(src[r][c])
 int launch_pad_copy(const float *src, int rows, int cols, float *dst, int rows_pad, int cols_pad, hipStream_t stream);
 // counting sort of positions 0..n-1 by ids[position] (mot_backward.hip); ws_ints: group_positions_ws_ints(n, rows) int32
