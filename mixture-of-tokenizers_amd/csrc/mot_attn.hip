@@ -1213,7 +1213,7 @@ size_t cross_attn_bwd_workspace_bytes(const MotCrossAttnDesc &d) { return attn_b
 //  B operand is row-major along the reduction: 625 against 730 us at 65 536 x 768 x 768)
 static int dense_gemm_kmajor(const float *rows, int64_t n, int Kc, const float *W, int Nout, float *out, hipStream_t stream, float *part = nullptr,
                              size_t part_n = 0, float *wt = nullptr) {
-    if (wt && n >= 4096 && gemm_rows_f32_256_usable(rows, Kc, n, wt, Kc, Kc, Nout)) {
+    if (wt && gemm_rows_f32_256_usable(rows, Kc, n, wt, Kc, Kc, Nout)) {   // (512 rows and more)
         if (int rc = launch_transpose_f32(W, Kc, Nout, wt, stream)) return rc;
         return launch_gemm_rows_f32_256(rows, Kc, n, wt, Kc, Kc, Nout, out, Nout, nullptr, false, stream);
     }

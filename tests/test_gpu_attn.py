@@ -147,6 +147,8 @@ def test_cross_attn_backward_vs_reference_autograd(mot, case, mode):
     (640, 7, 300, 53, "per_token", True, 9956, False),
     (384, 3, 300, 41, "per_token", False, 9957, False),        # 3 heads, bpt smaller than the head count
     (768, 4, 300, 45, "as_viewed", True, 9958, False),         # 6 heads, 4 keys: the slots of a position run over more than two queries
+    (256, 8, 300, 640, "as_viewed", True, 9967, False),        # 640 tokens: dy and dxq on the LDS-DMA product kernel (transposed weights)
+    (256, 4, 300, 160, "as_viewed", True, 9968, True),         # ... and dxkv, over the 640 kv positions of two id tensors
     (256, 2, 300, 19, "as_viewed", True, 9966, False),         # two keys per token: two live quads in the lane-per-key kernels (with ONE key the
                                                                # token-table and q_w gradients are exactly zero in the reference: nothing to scale a bar by)
     (768, 20, 300, 37, "as_viewed", True, 9959, False),        # more than 16 keys: the key-loop attention kernels
