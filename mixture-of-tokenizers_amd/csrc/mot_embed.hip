@@ -463,7 +463,7 @@ static int dispatch_nch(const MixArgs &A, int dtype, int64_t blocks, size_t lds,
 // v_readlane of the row's byte offset (a constant lane), one v_add, one ds_read_b128, two v_pk_add_f32 -- round 2's loop over a
 // run-time bpt with its scalar multiplies, branches and per-flag selects issued ~100 instructions per token and wave, and without
 // its output stores the kernel still took 2.7 of its 6.0 ms: instruction issue, 16 waves per CU.
-template <typename T, int U, int BPT, bool NORMB, bool ADD16 = false>   // ADD16 (T = float): MixArgs.add16
+template <typename T, int U, int BPT, bool NORMB, int ADD = 0>   // ADD (T = float): 1 = MixArgs.add16 (bf16 rows), 2 = the fp32 rows of out: out += result
 __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, int slice_cols, int nslices, int64_t tokens_per_part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *tab = (T *)lds_raw;                                   // [byte_rows][slice_cols]
@@ -507,7 +507,8 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
         if (chunk + 64 < w_hi) tokv_nx = chunk + 64 + lane < w_hi ? A.tokens[chunk + 64 + lane] : 0;
         const int nb = (int)min((int64_t)64, w_hi - chunk);
         typename Elem<T>::raw ar_nx[U];
-        uint2 old_nx[U];   // add16: the bf16 values the batch's results are added to, requested with the batch's rows
+        uint2 old_nx[U];   // ADD == 1: the bf16 values the batch's results are added to, requested with the batch's rows
+        float4v old32_nx[U];   // ADD == 2: the fp32 values
         int64_t id_nx = 0;
         auto request = [&](int b) {
 #pragma unroll
@@ -518,7 +519,8 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                     tok = 0;
                 }
                 ar_nx[u] = Elem<T>::load_raw(tok_table + (int64_t)tok * D + col0 + c);
-                if constexpr (ADD16) old_nx[u] = *(const uint2 *)(A.add16 + (chunk + min(b + u, nb - 1)) * D + col0 + c);
+                if constexpr (ADD == 1) old_nx[u] = *(const uint2 *)(A.add16 + (chunk + min(b + u, nb - 1)) * D + col0 + c);
+                if constexpr (ADD == 2) old32_nx[u] = *(const float4v *)(A.out + (chunk + min(b + u, nb - 1)) * D + col0 + c);
             }
             const int64_t at = (chunk + b) * A.bpt + lane;    // lane = (token of the batch, slot)
             id_nx = (lane < id_lanes && at < n_all * A.bpt) ? A.ids_a[at] : 0;
@@ -527,10 +529,12 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
         for (int b = 0; b < nb; b += U) {
             typename Elem<T>::raw ar[U];
             uint2 old[U];
+            float4v old32[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 ar[u] = ar_nx[u];
-                if constexpr (ADD16) old[u] = old_nx[u];
+                if constexpr (ADD == 1) old[u] = old_nx[u];
+                if constexpr (ADD == 2) old32[u] = old32_nx[u];
             }
             const int64_t idq = id_nx;
             if (b + U < nb) request(b + U);
@@ -571,7 +575,11 @@ __global__ __launch_bounds__(1024) void embed_mean_lds_kernel(const MixArgs A, i
                 vec_t acc = acc0 + acc1;
                 if (!pow2) acc = acc * inv_bpt;               // within an ulp of acc / bpt for the other slot counts
                 const vec_t x = Elem<T>::widen(ar[u]) * s_tok + acc * cb;
-                if constexpr (ADD16) {   // (character mixer with a bf16 result: h += residuals on the bf16 output of wo, mot_swa.hip)
+                if constexpr (ADD == 2) {   // (character mixer, fp32: h = wo y is there already; the product's own C += epilogue cost it 0.43 of 4.5 ms)
+                    if (b + u < nb) Elem<float>::storev_nt((float *)orow + (int64_t)u * D, old32[u] + x);
+                    continue;
+                }
+                if constexpr (ADD == 1) {   // (character mixer with a bf16 result: h += residuals on the bf16 output of wo, mot_swa.hip)
                     if (b + u < nb) {
                         const float4v h = {__uint_as_float(old[u].x << 16), __uint_as_float(old[u].x & 0xffff0000u), __uint_as_float(old[u].y << 16),
                                            __uint_as_float(old[u].y & 0xffff0000u)};
@@ -615,12 +623,27 @@ static int launch_mean_lds(MixArgs A, const MotEmbedMixDesc &d, int slice_cols, 
             static std::atomic<uint64_t> ok_{0};
             if (d.norm_byte) return set_error(MOT_EUNSUPPORTED, "embed_mix: add16 without norm_byte");
             if (d.bpt == 8) {
-                if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU, 8, false, true>, ok_, "embed_mean_lds_kernel")) return rc_lds;
-                hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU, 8, false, true>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
+                if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU, 8, false, 1>, ok_, "embed_mean_lds_kernel")) return rc_lds;
+                hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU, 8, false, 1>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
             } else {
                 static std::atomic<uint64_t> ok0_{0};
-                if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU, 0, false, true>, ok0_, "embed_mean_lds_kernel")) return rc_lds;
-                hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU, 0, false, true>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
+                if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU, 0, false, 1>, ok0_, "embed_mean_lds_kernel")) return rc_lds;
+                hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU, 0, false, 1>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
+            }
+            return check_launch("embed_mean_lds_kernel");
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (A.add_out) {   // out += result (see MixArgs)
+            if (d.norm_byte) return set_error(MOT_EUNSUPPORTED, "embed_mix: out += without norm_byte");
+            if (d.bpt == 8) {
+                static std::atomic<uint64_t> ok_{0};
+                if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU, 8, false, 2>, ok_, "embed_mean_lds_kernel")) return rc_lds;
+                hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU, 8, false, 2>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
+            } else {
+                static std::atomic<uint64_t> ok0_{0};
+                if (int rc_lds = ensure_max_dyn_lds((const void *)embed_mean_lds_kernel<T, kMeanU, 0, false, 2>, ok0_, "embed_mean_lds_kernel")) return rc_lds;
+                hipLaunchKernelGGL((embed_mean_lds_kernel<T, kMeanU, 0, false, 2>), dim3((unsigned)(parts * nslices)), dim3(1024), lds, stream, A, slice_cols, nslices, per);
             }
             return check_launch("embed_mean_lds_kernel");
         }
@@ -650,11 +673,13 @@ static int pick_unit(int64_t n_tokens) { return n_tokens >= 131072 ? 32 : 16; }
 
 bool embed_mix_mean_takes_add16(const MotEmbedMixDesc &d) { return d.dtype == MOT_F32 && mean_lds_slice(d) != 0; }
 
-int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream, __bf16 *add16) {
+int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream, __bf16 *add16, bool add_out) {
     MixArgs A;
     fill_mix_args(A, d);
     A.add16 = add16;
-    if (add16 && (d.dtype != MOT_F32 || !mean_lds_slice(d))) return set_error(MOT_EUNSUPPORTED, "embed_mix: add16 is a mode of the LDS-table MEAN kernel with fp32 tables");
+    A.add_out = add_out ? 1 : 0;
+    if ((add16 || add_out) && (d.dtype != MOT_F32 || !mean_lds_slice(d)))
+        return set_error(MOT_EUNSUPPORTED, "embed_mix: add16 / out += are modes of the LDS-table MEAN kernel with fp32 tables");
 
     const bool has_ids = d.mode != MOT_MIX_NOOP;
     const bool dual = has_ids && (d.id_source == MOT_IDS_FROM_TTB ? d.add_padded != 0 : d.ids_b != nullptr);

@@ -42,7 +42,7 @@ int launch_concat_rows(const int32_t *tokens, const int64_t *ids, int64_t n, con
                        int64_t byte_rows, int Db, int bpt, int norm_tok, const float *byte_rnorm, float eps, void *u, int K, int tok_lo, int byte_lo,
                        uint32_t *status, int dtype, hipStream_t stream);
 size_t embed_mix_workspace_bytes(const MotEmbedMixDesc &d);
-int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream, __bf16 *add16 = nullptr);   // SUM / MEAN / NOOP (add16: MixArgs.add16)
+int launch_embed_mix(const MotEmbedMixDesc &d, hipStream_t stream, __bf16 *add16 = nullptr, bool add_out = false);   // SUM / MEAN / NOOP (MixArgs.add16 / add_out)
 bool embed_mix_mean_takes_add16(const MotEmbedMixDesc &d);
 int launch_embed_mix_linear(const MotEmbedMixDesc &d, hipStream_t stream);  // CONCAT_LINEAR
 int launch_embed_mix_linear_ex(const MotEmbedMixDesc &d, const float *wt_prebuilt, int wt_cols, hipStream_t stream);

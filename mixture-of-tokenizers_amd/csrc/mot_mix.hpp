@@ -69,6 +69,7 @@ struct MixArgs {
     const float *byte_rnorm;  // workspace: 1/rms of every byte-table row (norm_byte)
     float *out;
     __bf16 *add16;            // LDS-table MEAN kernel, fp32 tables: the result is added to the bf16 rows here (fp32 sum, one rounding) instead of stored to out
+    int add_out;              // the same kernel: out += result (fp32 rows)
     int64_t *out_ids_padded, *out_ids_pulled, *counters;
     uint32_t *status;
     int tile_tokens, tiles_per_row;   // tile kernels (mot_linear.hip)
@@ -183,6 +184,7 @@ inline void fill_mix_args(MixArgs &A, const MotEmbedMixDesc &d) {
     A.byte_rnorm = nullptr;
     A.out = (float *)d.out;
     A.add16 = nullptr;
+    A.add_out = 0;
     A.out_ids_padded = d.out_ids_padded; A.out_ids_pulled = d.out_ids_pulled; A.counters = d.counters;
     A.status = d.status;
 }

@@ -168,23 +168,30 @@ def test_char_swa_bf16_tables(mot, matmul, T):
         assert (np.abs(got - plain) <= 3 * 2.0 ** -8 * np.maximum(np.abs(plain), np.sqrt((plain ** 2).mean())) + 2.0 ** -7 * np.abs(attn)).all()
 
 
-def test_char_swa_bf16_residual_paths_agree(mot):
-    """bf16 tables, two_residual: from 16 384 tokens on the residuals are added to the bf16 output of wo by the LDS-table MEAN kernel's
-    read-modify-write form, below that by the plain per-token kernel (what every other test of this file reaches).  One call over
-    2 x 8192 tokens against the same two batch rows in two calls: both add the same fp32 terms to the same bf16 values and round once,
-    in a different order of the character rows' sum -- equal but for roundings that sit on a boundary."""
+@pytest.mark.parametrize("tables", ["bf16", "fp32"])
+def test_char_swa_residual_paths_agree(mot, tables):
+    """two_residual: from 16 384 tokens on the residuals are added to the output of wo by the LDS-table MEAN kernel's read-modify-write
+    forms (bf16 rows with bf16 tables; fp32 rows, after a plain product, with fp32 tables), below that by the per-token kernel / by the
+    product's own C += after the MEAN kernel (what every other test of this file reaches).  One call over 2 x 8192 tokens against the
+    same two batch rows in two calls: the same terms in another order -- bf16: equal but for roundings that sit on a boundary; fp32:
+    within a few ulps of the sums' largest term."""
     B, T, c_v, d, H, hd, window = 2, 8192, 8, 256, 4, 64, 8
     c = case(31, B, T, c_v, d, H, hd, 900, 132)
-    b16 = lambda a: dev(a).bfloat16()
-    t = {k: (b16(v) if v.dtype == np.float32 else dev(v)) for k, v in c.items()}
+    cast = (lambda a: dev(a).bfloat16()) if tables == "bf16" else dev
+    t = {k: (cast(v) if v.dtype == np.float32 else dev(v)) for k, v in c.items()}
+    lam = lambda x: torch.tensor([x], device=DEV, dtype=torch.bfloat16 if tables == "bf16" else torch.float32)
     kw = dict(attn_norm_w=t["wa"], char_norm_w=t["wc"], wq=t["wq"], wk=t["wk"], wv=t["wv"], wo=t["wo"], n_heads=H, head_dim=hd, window=window,
-              version="two_residual", lambda_tok=torch.tensor([0.8], device=DEV).bfloat16(), lambda_char=torch.tensor([1.3], device=DEV).bfloat16())
+              version="two_residual", lambda_tok=lam(0.8), lambda_char=lam(1.3))
     whole = mot.functional.char_swa(t["toks"], t["cid"], t["Et"], t["Ec"], **kw)
     rows = torch.cat([mot.functional.char_swa(t["toks"][i:i + 1], t["cid"][i:i + 1], t["Et"], t["Ec"], **kw) for i in range(B)])
     mot.check_status()
-    assert whole.dtype == torch.bfloat16 and whole.shape == (B, T, d)
+    assert whole.shape == (B, T, d)
     a, b = host(whole.float()).astype(np.float64), host(rows.float()).astype(np.float64)
-    assert (np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(b), 2.0 ** -6)).all() and (a == b).mean() > 0.999, (np.abs(a - b).max(), (a == b).mean())
+    if tables == "bf16":
+        assert whole.dtype == torch.bfloat16
+        assert (np.abs(a - b) <= 2.0 ** -7 * np.maximum(np.abs(b), 2.0 ** -6)).all() and (a == b).mean() > 0.999, (np.abs(a - b).max(), (a == b).mean())
+    else:
+        assert whole.dtype == torch.float32 and (np.abs(a - b) <= 4e-6 * np.maximum(np.abs(b), 1.0)).all(), np.abs(a - b).max()
 
 
 @pytest.mark.parametrize("tables", ["fp32", "bf16"])
